@@ -1,0 +1,38 @@
+# Builds everything in-tree for gfx950 (MI355X).  No GPU is needed to build.
+#   pathtracer_amd/lib/libmi_tracer.so  HIP kernels + C-ABI (include/mi_tracer.h)
+#   pathtracer_amd/lib/libpt_host.so    host side: .ray parser, BVH build, Tracer/HipTracer
+#   pathtracer_amd/bin/ray              command-line renderer
+#   oracle/liboracle.so                 CPU oracle (test infrastructure only)
+HIPCC ?= /opt/rocm/bin/hipcc
+CXX ?= g++
+ARCH ?= gfx950
+# -ffp-contract=off: the numerics contract — no FMA contraction, so
+# device results match the oracle bit for bit.
+HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function
+CXXFLAGS = -O2 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -pthread
+LIB = pathtracer_amd/lib
+BIN = pathtracer_amd/bin
+HOST_SRC = pathtracer_amd/host/scene.cpp pathtracer_amd/host/ray_parser.cpp pathtracer_amd/host/tracer.cpp \
+           pathtracer_amd/host/image_io.cpp pathtracer_amd/host/host_capi.cpp
+HOST_HDR = pathtracer_amd/host/scene.h pathtracer_amd/host/tracer.h pathtracer_amd/host/vec4.h include/mi_tracer.h
+
+all: $(LIB)/libmi_tracer.so $(LIB)/libpt_host.so $(BIN)/ray oracle/liboracle.so
+
+$(LIB)/libmi_tracer.so: pathtracer_amd/csrc/mi_tracer.hip pathtracer_amd/csrc/mi_kernels.h include/mi_tracer.h
+	@mkdir -p $(LIB)
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ pathtracer_amd/csrc/mi_tracer.hip
+
+$(LIB)/libpt_host.so: $(HOST_SRC) $(HOST_HDR) $(LIB)/libmi_tracer.so
+	$(CXX) $(CXXFLAGS) -shared -o $@ $(HOST_SRC) -L$(LIB) -lmi_tracer -Wl,-rpath,'$$ORIGIN'
+
+$(BIN)/ray: pathtracer_amd/host/ray_main.cpp $(LIB)/libpt_host.so
+	@mkdir -p $(BIN)
+	$(CXX) $(CXXFLAGS) -o $@ pathtracer_amd/host/ray_main.cpp -L$(LIB) -lpt_host -lmi_tracer -Wl,-rpath,'$$ORIGIN/../lib'
+
+oracle/liboracle.so: oracle/oracle.cpp include/mi_tracer.h
+	$(MAKE) -C oracle
+
+clean:
+	rm -rf $(LIB) $(BIN) oracle/liboracle.so
+
+.PHONY: all clean

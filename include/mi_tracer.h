@@ -1,0 +1,193 @@
+/*
+ * mi_tracer.h — C-ABI of the MI355X-native tracer backend (libmi_tracer.so).
+ *
+ * This is the drop-in boundary that sits UNDER a `Tracer` subclass (reference
+ * interface: src/tracer.h:19-52, pure virtuals traceImage/waitRender at :35-37).
+ * The reference's GPU backend crosses its device boundary inside
+ * GpuTracer::traceImage (src/GpuTracer.cu:161-189) with C++ objects deep-copied
+ * by Scene::clone (src/scene/scene.cu:3-13) and
+ * BoundedVolumeHierarchy::flatten_clone (src/scene/bvh.cu:395-415).  Here that
+ * boundary is a plain C interface: POD structs, borrowed host pointers, sizes,
+ * status codes.  No C++ types, no exceptions, no torch types cross it.
+ *
+ * All colour/vector data is fp32.  "float4" below means 4 consecutive floats.
+ */
+#ifndef MI_TRACER_H
+#define MI_TRACER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mi_ctx mi_ctx;
+
+typedef enum mi_status {
+    MI_OK = 0,
+    MI_ERR_INVALID = 1,   /* bad argument (NULL, zero size, inconsistent scene) */
+    MI_ERR_NO_DEVICE = 2, /* no usable HIP device / bad device id              */
+    MI_ERR_HIP = 3,       /* a hip* call failed; see mi_last_error()           */
+    MI_ERR_NO_SCENE = 4,  /* render called before mi_scene_upload              */
+    MI_ERR_OOM = 5        /* device allocation failed                          */
+} mi_status;
+
+/*
+ * Flattened scene, structure-of-arrays.  Replaces what the reference uploads
+ * with Scene::clone / flatten_clone (src/scene/scene.cu:3-13,
+ * src/scene/bvh.cu:395-415): Cluster[2N-1] AoS nodes of 64 B
+ * (src/scene/bvh.h:19-34) and Geometry[N] AoS records of 480 B
+ * (src/scene/geometry.h:11-48).
+ *
+ * BVH: binary, one primitive per leaf like the reference's (bvh.cu:72-76), but
+ * only INTERIOR nodes are stored; a node holds the boxes of both children (the
+ * reference also tests both child boxes at the parent, bvh.cu:7-8,190-191).
+ *   node = 16 floats (64 B):
+ *     [0..2] left  bmin   [3..5]  left  bmax
+ *     [6..8] right bmin   [9..11] right bmax
+ *     [12] left  child ref (int32 bits)   [13] right child ref (int32 bits)
+ *     [14],[15] reserved (0)
+ *   child ref >= 0 : index of an interior node
+ *   child ref <  0 : leaf holding primitive slot ~ref
+ * Primitive slots: [0, n_tri) are triangles, [n_tri, n_tri+n_sph) are spheres
+ * (slot - n_tri indexes the sphere arrays).
+ * root_ref: ref of the root (an interior node index, a leaf ref for a
+ * one-primitive scene — bvh.cu:182-183 — or ignored when n_tri+n_sph == 0).
+ */
+typedef struct mi_scene_soa {
+    uint32_t n_nodes;
+    const float *nodes;           /* n_nodes * 16 floats                            */
+    int32_t root_ref;
+
+    uint32_t n_tri;
+    const float *tri_v0;          /* float4[n_tri]  vertex 0   (trimesh.cu:33,88)   */
+    const float *tri_uinv;        /* float4[n_tri]  uInv       (trimesh.cu:37)      */
+    const float *tri_vinv;        /* float4[n_tri]  vInv       (trimesh.cu:38)      */
+    const float *tri_ninv;        /* float4[n_tri]  nInv       (trimesh.cu:39)      */
+    const float *tri_normal;      /* float4[n_tri]  face normal (trimesh.cu:24,36)  */
+    const uint32_t *tri_mat;      /* uint32[3*n_tri] material ids of vertex a,b,c;
+                                     all three equal when the mesh has no per-vertex
+                                     materials (trimesh.cu:32,40-45)                */
+    const uint8_t *tri_has_vmat;  /* uint8[n_tri]   hasMaterials (trimesh.cu:41)    */
+
+    uint32_t n_sph;
+    const float *sph_center_radius; /* float4[n_sph] (cx,cy,cz,radius) sphere.h:13-15 */
+    const uint32_t *sph_mat;        /* uint32[n_sph]                                 */
+
+    uint32_t n_mat;
+    const float *materials;       /* n_mat * 20 floats: ke,kd,kr,kt,index as float4
+                                     each (material.h:129-133)                      */
+
+    const int32_t *prim_id;       /* int32[n_tri+n_sph] stable primitive id (parse
+                                     order) of each slot; used to break exact-t ties
+                                     independently of BVH order                     */
+
+    float cam_eye[4];             /* camera.h:33-36 / camera.cu:60-65               */
+    float cam_u[4];
+    float cam_v[4];
+    float cam_look[4];
+} mi_scene_soa;
+
+/* Render parameters.  samples_per_dim and depth have the reference's meaning:
+ * -s N -> N*N paths per pixel on a regular grid (CpuTracer.cu:99-109);
+ * -r D -> a path casts up to D+2 rays (CpuTracer.cu:119-131).                      */
+typedef struct mi_render_params {
+    int32_t width;
+    int32_t height;
+    int32_t samples_per_dim;
+    int32_t depth;
+    uint64_t seed;        /* key of the counter-based RNG (replaces the unseedable
+                             mt19937 of CpuTracer.cu:24-35)                         */
+    int32_t tile_w;       /* shard tile size in pixels; 0 -> 32 (CpuTracer.cu:55)   */
+    int32_t tile_h;
+    int32_t shard_rank;   /* this context renders tiles k with k % shard_count ==   */
+    int32_t shard_count;  /*   shard_rank (row-major tile index); 0/1 -> everything */
+    int64_t batch_paths;  /* max paths in flight per wavefront batch; 0 -> default  */
+} mi_render_params;
+
+typedef struct mi_stats {
+    uint64_t rays_cast;      /* closest-hit queries issued (primary + bounce)       */
+    uint64_t paths;          /* paths started                                       */
+    double ms_total;         /* first launch -> outputs complete (HIP events)       */
+    double ms_extend;        /* sum over launches of the BVH extend kernel          */
+    double ms_shade;         /* sum over launches of the shade+compact kernel       */
+    double ms_other;         /* generate + resolve                                  */
+    uint32_t extend_launches;
+    uint32_t batches;
+} mi_stats;
+
+/* Create a context on HIP device `device_id`.  One context = one GPU; multi-GPU
+ * jobs use one process (and one context) per GPU.  Replaces the implicit device-0
+ * state of GpuTracer (GpuTracer.cu:165-181). */
+mi_status mi_ctx_create(int device_id, mi_ctx **out);
+
+/* Free all device memory of the context (the reference never frees; GpuTracer.cu). */
+void mi_ctx_destroy(mi_ctx *ctx);
+
+/* Copy the flattened scene to the device.  Host pointers are borrowed for the call
+ * only.  Replaces Scene::clone (scene.cu:3-13) + flatten_clone (bvh.cu:395-415). */
+mi_status mi_scene_upload(mi_ctx *ctx, const mi_scene_soa *scene);
+
+/* Render (this shard of) the image: the whole of GpuTracer::traceImage
+ * (GpuTracer.cu:161-189) incl. the host setPixel loop (:186-188, tracer.cu:95-100).
+ *   rgba_mean_out : float4[width*height] mean clamped radiance per pixel (what
+ *                   setPixel receives), row 0 = bottom row; may be NULL.
+ *   rgb8_out      : uint8[width*height*3] tonemapped bytes at (i + j*width)*3
+ *                   (tracer.cu:96); may be NULL.
+ * Pixels of tiles this shard does not own are left untouched in both buffers.
+ * Synchronous.  Both outputs are HOST pointers. */
+mi_status mi_render(mi_ctx *ctx, const mi_render_params *params,
+                    float *rgba_mean_out, uint8_t *rgb8_out, mi_stats *stats);
+
+/* Same render, outputs left in DEVICE memory in shard-local order (for an RCCL
+ * gather without a host round-trip).  Local pixel q of the shard = owned tile
+ * q / (tile_w*tile_h) (j-th owned tile is global tile shard_rank + j*shard_count),
+ * offset q % (tile_w*tile_h) inside the tile, row-major.
+ *   d_rgba_mean : device float4[mi_shard_pixels()] or NULL
+ *   d_rgba8     : device uint8[4*mi_shard_pixels()] (r,g,b,255) or NULL
+ * Pixels of edge tiles that fall outside the image are written as zeros.
+ * `stream` is a hipStream_t (NULL = default stream).  The call enqueues work and
+ * synchronises the stream before returning. */
+mi_status mi_render_device(mi_ctx *ctx, const mi_render_params *params,
+                           void *d_rgba_mean, void *d_rgba8, void *stream,
+                           mi_stats *stats);
+
+/* Number of local pixel slots (owned tiles * tile_w * tile_h) of a shard. */
+int64_t mi_shard_pixels(const mi_render_params *params);
+
+/* Scatter gathered shard-local RGBA8 buffers (shard r at d_gathered +
+ * r*4*shard_pixels_max bytes, each laid out as mi_render_device writes them) into a
+ * bottom-up RGB8 frame on the HOST (tracer.cu:96 layout).  Used by rank 0 after the
+ * gather.  d_gathered is a DEVICE pointer. */
+mi_status mi_assemble_rgb8(mi_ctx *ctx, const mi_render_params *params,
+                           const void *d_gathered, int64_t shard_stride_pixels,
+                           uint8_t *rgb8_out);
+
+/* Primary-ray closest hit only (parity probe; the reference has no such entry —
+ * it corresponds to Camera::rayThrough (camera.cu:6-16) + Scene::intersect
+ * (scene.h:70-72) per sample of CpuTracer::tracePixel (CpuTracer.cu:99-109)).
+ * Outputs are HOST arrays of width*height*samples_per_dim^2 entries, index
+ * (j*width + i)*spp + (sx*samples_per_dim + sy):
+ *   prim_id_out : stable primitive id, -1 on miss
+ *   t_out       : hit distance (ISECT_NO_HIT 12345678.9f on miss, ray.h:14)
+ *   n_out       : float3 geometric normal (0 on miss); may be NULL              */
+mi_status mi_trace_primary(mi_ctx *ctx, int32_t width, int32_t height,
+                           int32_t samples_per_dim, int32_t *prim_id_out,
+                           float *t_out, float *n_out);
+
+/* Closest hit for caller-supplied rays (parity probe for bounce rays).
+ * rays: float[n*6] (ox,oy,oz,dx,dy,dz), HOST.  Outputs as mi_trace_primary. */
+mi_status mi_trace_rays(mi_ctx *ctx, int64_t n, const float *rays,
+                        int32_t *prim_id_out, float *t_out, float *n_out);
+
+/* Thread-local description of the last error returned on this thread. */
+const char *mi_last_error(void);
+
+/* Library/ABI version (bumped on any struct change). */
+int mi_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI_TRACER_H */

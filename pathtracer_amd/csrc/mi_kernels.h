@@ -1,0 +1,575 @@
+// mi_kernels.h — hand-written HIP kernels of the wavefront path tracer (gfx950).
+//
+// Stages (one launch each per bounce level; all paths of a batch are at the same
+// level k in iteration k):
+//   k_generate : camera rays for a batch of (pixel, sample) slots   [camera.cu:6-16, CpuTracer.cu:99-109]
+//   k_extend   : BVH closest hit, LDS short stack, per-wave dynamic  [bvh.cu:3-10,178-207, bbox.cu:15-34,
+//                work fetch                                           trimesh.cu:87-121, sphere.cu:5-35]
+//   k_shade    : material branch, next ray, termination, wave-ballot [CpuTracer.cu:119-186, :37-53]
+//                compaction of survivors into the next queue
+//   k_resolve  : per-pixel mean in fixed sample order + Hable tonemap [CpuTracer.cu:108, tracer.cu:20-30,95-100]
+//
+// Numerics contract: fp32, no FMA contraction (-ffp-contract=off),
+// IEEE divide/sqrt, operations in the order of the cited reference lines, so the
+// results are bit-identical to oracle/oracle.cpp on the same inputs.  The w lane
+// of positions/directions/normals is identically +0 in every scene the loader
+// can produce (vec.h:18, Parser.cu:339,777-786), so those are carried as 3 lanes;
+// throughput, weights and radiance keep all 4 lanes (vec.h:15 broadcasts into w).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define MI_BLOCK 256          // threads per workgroup = 4 waves of 64
+#define MI_LDS_STACK 32       // traversal stack entries per lane held in LDS
+#define MI_MAX_STACK 64       // deepest tree the uploader accepts
+#define MI_NO_HIT 12345678.9f // ray.h:14
+#define MI_EPS 0.00001f       // ray.h:12
+
+struct DevScene {
+    const float4 *nodes; // 4 x float4 per interior node (layout: include/mi_tracer.h)
+    const float4 *tri;   // 4 x float4 per triangle slot: v0, uInv, vInv, nInv
+    const float4 *tri_normal;
+    const uint32_t *tri_mat; // 3 per triangle
+    const uint8_t *tri_has_vmat;
+    const float4 *sph; // (cx, cy, cz, r)
+    const uint32_t *sph_mat;
+    const float4 *mats; // 5 x float4 per material
+    const int32_t *prim_id;
+    int32_t root_ref;
+    uint32_t n_tri, n_sph;
+    float4 eye, u, v, look;
+};
+
+struct f3 {
+    float x, y, z;
+};
+__device__ __forceinline__ f3 mk3(float x, float y, float z) { return f3{x, y, z}; }
+__device__ __forceinline__ f3 xyz(const float4 &a) { return f3{a.x, a.y, a.z}; }
+__device__ __forceinline__ f3 operator+(f3 a, f3 b) { return f3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ f3 operator-(f3 a, f3 b) { return f3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ f3 operator-(f3 a) { return f3{-a.x, -a.y, -a.z}; }
+__device__ __forceinline__ f3 operator*(f3 a, float f) { return f3{a.x * f, a.y * f, a.z * f}; }
+__device__ __forceinline__ f3 operator*(float f, f3 a) { return f3{f * a.x, f * a.y, f * a.z}; }
+// vec.h:188-190 sums lanes left to right; the w*w product is +0 and adding it
+// changes nothing (only the sign of an exact zero sum, which no test observes).
+__device__ __forceinline__ float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ f3 cross3(f3 a, f3 b) { // vec.h:204-208
+    return f3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+// vec.h:200-202 with rsqrtf(x) := 1/sqrt(x), both IEEE (oracle deviation D2).
+__device__ __forceinline__ f3 normalize3(f3 a) { return a * (1.0f / __builtin_sqrtf(dot3(a, a))); }
+
+__device__ __forceinline__ float4 mul4(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+__device__ __forceinline__ float4 mul4(float4 a, float f) { return make_float4(a.x * f, a.y * f, a.z * f, a.w * f); }
+__device__ __forceinline__ float4 mul4(float f, float4 a) { return make_float4(f * a.x, f * a.y, f * a.z, f * a.w); }
+__device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float length2_4(float4 a) { return a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w; }
+
+// ---------------------------------------------------------------- Philox4x32-10
+// Counter-based RNG shared with the oracle (deviation D1): counter = (path_lo,
+// path_hi, level, 0), key = seed.
+__device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
+        uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+        uint32_t n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
+        c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+}
+__device__ __forceinline__ float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
+
+// sin/cos of p in [0, 2*pi]: quadrant reduction with a two-constant pi/2 and
+// degree-7/8 polynomials in explicit fmaf form (oracle deviation D3, mode 1).
+__device__ __forceinline__ void sincos_poly(float p, float &s_out, float &c_out) {
+    float k = __builtin_rintf(p * 0.636619772f);
+    int q = (int)k;
+    float r = __builtin_fmaf(-k, 1.5707962513e+0f, p);
+    r = __builtin_fmaf(-k, 7.5497894159e-8f, r);
+    float z = r * r;
+    float sp = __builtin_fmaf(__builtin_fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f);
+    float s = __builtin_fmaf(sp * z, r, r);
+    float cp = __builtin_fmaf(__builtin_fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f);
+    float c = __builtin_fmaf(cp * z, z, __builtin_fmaf(-0.5f, z, 1.0f));
+    switch (q & 3) {
+        case 0: s_out = s; c_out = c; break;
+        case 1: s_out = c; c_out = -s; break;
+        case 2: s_out = -s; c_out = -c; break;
+        default: s_out = -c; c_out = s; break;
+    }
+}
+
+// ------------------------------------------------------------ shard geometry
+struct ShardGeom {
+    int32_t width, height, tile_w, tile_h, tiles_x, n_tiles, rank, count;
+    int32_t samples; // per dimension
+};
+// Local pixel q (tile-major, row-major inside the tile; the order documented for
+// mi_render_device) -> image pixel.  Returns false for pixels of edge tiles that
+// fall outside the image.
+__device__ __forceinline__ bool local_to_pixel(const ShardGeom &g, int64_t q, int &px, int &py) {
+    int tpix = g.tile_w * g.tile_h;
+    int64_t j = q / tpix;
+    int off = (int)(q - j * tpix);
+    int64_t gt = g.rank + j * (int64_t)g.count;
+    int tx = (int)(gt % g.tiles_x), ty = (int)(gt / g.tiles_x);
+    px = tx * g.tile_w + off % g.tile_w;
+    py = ty * g.tile_h + off / g.tile_w;
+    return gt < g.n_tiles && px < g.width && py < g.height;
+}
+// Path slots of a batch walk each tile in 8x8 sub-blocks so that one wave (64
+// consecutive slots) covers an 8x8 pixel patch: coherent primary rays.  `lp` is
+// the position inside the batch; returns the local pixel it renders.
+__device__ __forceinline__ int64_t slot_to_local(const ShardGeom &g, int64_t lp) {
+    if ((g.tile_w & 7) || (g.tile_h & 7)) return lp;
+    int tpix = g.tile_w * g.tile_h;
+    int64_t j = lp / tpix;
+    int off = (int)(lp - j * tpix);
+    int sub = off >> 6, in = off & 63;
+    int sbx = sub % (g.tile_w >> 3), sby = sub / (g.tile_w >> 3);
+    int x = sbx * 8 + (in & 7), y = sby * 8 + (in >> 3);
+    return j * tpix + y * g.tile_w + x;
+}
+
+// Wave-level queue append: ballot + prefix popcount + one atomic per wave.
+__device__ __forceinline__ void queue_append(bool alive, uint32_t slot, uint32_t *queue, uint32_t *count) {
+    unsigned long long mask = __ballot(alive);
+    if (mask == 0) return;
+    int lane = threadIdx.x & 63;
+    int leader = __ffsll((long long)mask) - 1;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(count, (uint32_t)__popcll(mask));
+    base = __shfl(base, leader, 64);
+    if (alive) queue[base + __popcll(mask & ((1ull << lane) - 1ull))] = slot;
+}
+
+// ------------------------------------------------------------------ generate
+// One thread per slot of the batch; slot = sample * npix + lp.
+__global__ void __launch_bounds__(MI_BLOCK)
+k_generate(DevScene sc, ShardGeom g, int64_t pix0, int32_t npix, float4 *ray_o, float4 *ray_d, float4 *thr,
+           float4 *path_out, uint32_t *queue, uint32_t *count) {
+    int64_t i = (int64_t)blockIdx.x * MI_BLOCK + threadIdx.x;
+    int spp = g.samples * g.samples;
+    bool alive = false;
+    if (i < (int64_t)npix * spp) {
+        int samp = (int)(i / npix);
+        int lp = (int)(i - (int64_t)samp * npix);
+        int px, py;
+        alive = local_to_pixel(g, slot_to_local(g, pix0 + lp), px, py);
+        if (alive) {
+            int sx = samp / g.samples, sy = samp - sx * g.samples;
+            // CpuTracer.cu:103-105
+            float xx = float(px) - 0.5f + (1 + 2 * sx) / (2.0f * g.samples);
+            float yy = float(py) - 0.5f + (1 + 2 * sy) / (2.0f * g.samples);
+            float x = xx / float(g.width), y = yy / float(g.height);
+            x -= 0.5f; // camera.cu:11-12
+            y -= 0.5f;
+            f3 dir = normalize3(xyz(sc.look) + x * xyz(sc.u) + y * xyz(sc.v)); // camera.cu:13
+            ray_o[i] = make_float4(sc.eye.x, sc.eye.y, sc.eye.z, 0.0f);
+            ray_d[i] = make_float4(dir.x, dir.y, dir.z, 0.0f);
+            thr[i] = make_float4(1.0f, 1.0f, 1.0f, 1.0f); // traceRay(r, 1, depth), CpuTracer.cu:114
+        } else {
+            path_out[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+    }
+    queue_append(alive, (uint32_t)i, queue, count);
+}
+
+// Rays for mi_trace_primary: full image, index (j*W+i)*spp + sx*s+sy.
+__global__ void __launch_bounds__(MI_BLOCK)
+k_generate_primary(DevScene sc, int width, int height, int samples, int64_t first, int64_t n, float4 *ray_o, float4 *ray_d) {
+    int64_t i = (int64_t)blockIdx.x * MI_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    int64_t gidx = first + i;
+    int spp = samples * samples;
+    int samp = (int)(gidx % spp);
+    int64_t pix = gidx / spp;
+    int px = (int)(pix % width), py = (int)(pix / width);
+    int sx = samp / samples, sy = samp - sx * samples;
+    float xx = float(px) - 0.5f + (1 + 2 * sx) / (2.0f * samples);
+    float yy = float(py) - 0.5f + (1 + 2 * sy) / (2.0f * samples);
+    float x = xx / float(width), y = yy / float(height);
+    x -= 0.5f;
+    y -= 0.5f;
+    f3 dir = normalize3(xyz(sc.look) + x * xyz(sc.u) + y * xyz(sc.v));
+    ray_o[i] = make_float4(sc.eye.x, sc.eye.y, sc.eye.z, 0.0f);
+    ray_d[i] = make_float4(dir.x, dir.y, dir.z, 0.0f);
+}
+
+// ------------------------------------------------------------------- extend
+struct Hit {
+    float t, u, v;
+    int slot;
+};
+
+// Exact-t ties are resolved as a visit in ascending primitive id would resolve
+// them (triangle accepts t <= best, trimesh.cu:96; sphere needs t < best,
+// sphere.cu:22,28), so the result does not depend on traversal order.
+__device__ __forceinline__ bool tie_allows(const DevScene &sc, int best_slot, int cand_slot, bool cand_is_tri) {
+    if (best_slot < 0) return cand_is_tri;
+    int cid = sc.prim_id[cand_slot], bid = sc.prim_id[best_slot];
+    bool best_is_sphere = (uint32_t)best_slot >= sc.n_tri;
+    if (cand_is_tri) return best_is_sphere ? true : (cid > bid);
+    return best_is_sphere ? (cid < bid) : false;
+}
+
+__device__ __forceinline__ void tri_test(const DevScene &sc, int slot, f3 o, f3 d, Hit &h) { // trimesh.cu:87-121
+    const float4 *rec = sc.tri + 4 * (size_t)slot;
+    float4 v0 = rec[0], ni = rec[3];
+    f3 p = o - xyz(v0);
+    float pz = dot3(xyz(ni), p);
+    float dz = dot3(xyz(ni), d);
+    if ((pz < 0) == (dz < 0)) return;
+    float t = -pz / dz;
+    if (t > h.t) return;
+    if (t == h.t && !tie_allows(sc, h.slot, slot, true)) return;
+    float4 ui = rec[1], vi = rec[2];
+    f3 hit = p + t * d;
+    float u = dot3(xyz(ui), hit);
+    float v = dot3(xyz(vi), hit);
+    if (u < 0 || u > 1 || v < 0 || v > 1 || u + v > 1) return;
+    h.t = t; h.u = u; h.v = v; h.slot = slot;
+}
+
+__device__ __forceinline__ void sphere_test(const DevScene &sc, int slot, f3 o, f3 d, Hit &h) { // sphere.cu:5-35
+    float4 cr = sc.sph[slot - (int)sc.n_tri];
+    f3 dir = normalize3(d);
+    f3 to = xyz(cr) - o;
+    float dt = dot3(dir, to);
+    float disc = dt * dt - dot3(to, to) + cr.w * cr.w;
+    if (disc < 0) return;
+    disc = __builtin_sqrtf(disc);
+    float t2 = dt + disc;
+    if (t2 < MI_EPS) return;
+    float t1 = dt - disc;
+    float t;
+    if (t1 > MI_EPS && (t1 < h.t || (t1 == h.t && tie_allows(sc, h.slot, slot, false)))) t = t1;
+    else if (t2 < h.t || (t2 == h.t && tie_allows(sc, h.slot, slot, false))) t = t2;
+    else return;
+    h.t = t; h.u = 0.0f; h.v = 0.0f; h.slot = slot;
+}
+
+__device__ __forceinline__ void prim_test(const DevScene &sc, int slot, f3 o, f3 d, Hit &h) { // geometry.h:26-29
+    if ((uint32_t)slot >= sc.n_tri) sphere_test(sc, slot, o, d, h);
+    else tri_test(sc, slot, o, d, h);
+}
+
+// bbox.cu:15-34.  EXACT keeps the reference's `(a<b?a:b)` macros (a NaN operand
+// yields the second operand); the fast form uses v_min/v_max, which is the same
+// function whenever no operand is NaN — guaranteed when 1/d is finite on all axes.
+template <bool EXACT>
+__device__ __forceinline__ bool slab(f3 bmin, f3 bmax, f3 o, f3 inv, float tmax, float &tmin_out) {
+    float t10 = (bmin.x - o.x) * inv.x, t11 = (bmin.y - o.y) * inv.y, t12 = (bmin.z - o.z) * inv.z;
+    float t20 = (bmax.x - o.x) * inv.x, t21 = (bmax.y - o.y) * inv.y, t22 = (bmax.z - o.z) * inv.z;
+    float tmin = -1.0e38f;
+    if (EXACT) {
+#define MI_MIN(a, b) ((a) < (b) ? (a) : (b))
+#define MI_MAX(a, b) ((a) < (b) ? (b) : (a))
+        tmin = MI_MAX(tmin, MI_MIN(t10, t20));
+        tmin = MI_MAX(tmin, MI_MIN(t11, t21));
+        tmin = MI_MAX(tmin, MI_MIN(t12, t22));
+        tmax = MI_MIN(tmax, MI_MAX(t10, t20));
+        tmax = MI_MIN(tmax, MI_MAX(t11, t21));
+        tmax = MI_MIN(tmax, MI_MAX(t12, t22));
+#undef MI_MIN
+#undef MI_MAX
+    } else {
+        tmin = fmaxf(fmaxf(fmaxf(tmin, fminf(t10, t20)), fminf(t11, t21)), fminf(t12, t22));
+        tmax = fminf(fminf(fminf(tmax, fmaxf(t10, t20)), fmaxf(t11, t21)), fmaxf(t12, t22));
+    }
+    tmin_out = tmin;
+    return tmin <= tmax && tmax > 0;
+}
+
+// Closest hit of one ray.  `stack` points at this lane's column of the LDS stack
+// (stride MI_BLOCK ints), `ovf` at its column of the global overflow (stride
+// ovf_stride).
+template <bool EXACT>
+__device__ __forceinline__ void traverse(const DevScene &sc, f3 o, f3 d, f3 inv, Hit &h, int *stack, int *ovf, size_t ovf_stride) {
+    int cur = sc.root_ref;
+    int sp = 0;
+    for (;;) {
+        const float4 *nd = sc.nodes + 4 * (size_t)cur;
+        float4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
+        float tminL, tminR;
+        bool hitL = slab<EXACT>(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), o, inv, h.t, tminL);
+        bool hitR = slab<EXACT>(mk3(n1.z, n1.w, n2.x), mk3(n2.y, n2.z, n2.w), o, inv, h.t, tminR);
+        int l = __float_as_int(n3.x), r = __float_as_int(n3.y);
+        if (hitL && l < 0) prim_test(sc, ~l, o, d, h);
+        if (hitR && r < 0) prim_test(sc, ~r, o, d, h);
+        // A child whose entry distance is already behind the best hit cannot
+        // contain a closer one (the reference re-tests the right box after the
+        // left subtree, bvh.cu:7-8, with the same outcome).
+        bool goL = hitL && l >= 0 && tminL <= h.t;
+        bool goR = hitR && r >= 0 && tminR <= h.t;
+        if (goL && goR) {
+            if (tminR < tminL) { int tmp = l; l = r; r = tmp; }
+            if (sp < MI_LDS_STACK) stack[sp * MI_BLOCK] = r;
+            else ovf[(size_t)(sp - MI_LDS_STACK) * ovf_stride] = r;
+            sp++;
+            cur = l;
+        } else if (goL) {
+            cur = l;
+        } else if (goR) {
+            cur = r;
+        } else {
+            if (sp == 0) break;
+            sp--;
+            cur = sp < MI_LDS_STACK ? stack[sp * MI_BLOCK] : ovf[(size_t)(sp - MI_LDS_STACK) * ovf_stride];
+        }
+    }
+}
+
+// Persistent waves: each wave fetches 64 queue entries at a time from a shared
+// cursor until the queue is drained (every wave reaches the exit test).
+// queue == nullptr means the identity queue (slot = index).
+__global__ void __launch_bounds__(MI_BLOCK)
+k_extend(DevScene sc, const uint32_t *queue, const uint32_t *count_ptr, uint32_t fixed_count, uint32_t *cursor,
+         const float4 *ray_o, const float4 *ray_d, float4 *hits, int *ovf) {
+    __shared__ int lds_stack[MI_LDS_STACK * MI_BLOCK];
+    const uint32_t n = count_ptr ? *count_ptr : fixed_count;
+    const int lane = threadIdx.x & 63;
+    int *stack = lds_stack + threadIdx.x;
+    const size_t ovf_stride = (size_t)gridDim.x * MI_BLOCK;
+    int *my_ovf = ovf + (size_t)blockIdx.x * MI_BLOCK + threadIdx.x;
+    const bool empty_scene = sc.n_tri + sc.n_sph == 0;
+    for (;;) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(cursor, 64u);
+        base = __shfl(base, 0, 64);
+        if (base >= n) break;
+        uint32_t i = base + lane;
+        if (i >= n) continue;
+        uint32_t slot = queue ? queue[i] : i;
+        float4 o4 = ray_o[slot], d4 = ray_d[slot];
+        f3 o = xyz(o4), d = xyz(d4);
+        f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z); // ray.h:53-57,79-82
+        Hit h{MI_NO_HIT, 0.0f, 0.0f, -1};
+        if (!empty_scene) {                                  // bvh.cu:174-176,180-181
+            if (sc.root_ref < 0) {                           // bvh.cu:182-183
+                prim_test(sc, ~sc.root_ref, o, d, h);
+            } else {
+                bool finite = __builtin_isfinite(inv.x) && __builtin_isfinite(inv.y) && __builtin_isfinite(inv.z);
+                if (finite) traverse<false>(sc, o, d, inv, h, stack, my_ovf, ovf_stride);
+                else traverse<true>(sc, o, d, inv, h, stack, my_ovf, ovf_stride);
+            }
+        }
+        hits[slot] = make_float4(h.t, __int_as_float(h.slot), h.u, h.v);
+    }
+}
+
+// -------------------------------------------------------------------- shade
+struct DMat {
+    float4 ke, kd, kr, kt;
+    float index;
+};
+__device__ __forceinline__ DMat load_mat(const DevScene &sc, uint32_t id) {
+    const float4 *m = sc.mats + 5 * (size_t)id;
+    return DMat{m[0], m[1], m[2], m[3], m[4].x};
+}
+
+// Geometric normal and material at a hit (trimesh.cu:107-119, sphere.cu:23-32).
+__device__ __forceinline__ void hit_surface(const DevScene &sc, int slot, float t, float u, float v, f3 o, f3 d, f3 &N, DMat &m) {
+    if ((uint32_t)slot >= sc.n_tri) {
+        int k = slot - (int)sc.n_tri;
+        float4 cr = sc.sph[k];
+        N = normalize3((o + (t * d)) - xyz(cr)); // ray.h:67, sphere.cu:26,31
+        m = load_mat(sc, sc.sph_mat[k]);
+    } else {
+        N = xyz(sc.tri_normal[slot]);
+        const uint32_t *mid = sc.tri_mat + 3 * (size_t)slot;
+        if (sc.tri_has_vmat[slot]) { // trimesh.cu:110-116 with material.h:91-100,137-146
+            float w = 1 - u - v;     // trimesh.cu:102
+            DMat a = load_mat(sc, mid[0]), b = load_mat(sc, mid[1]), c = load_mat(sc, mid[2]);
+            m.ke = add4(add4(mul4(a.ke, w), mul4(b.ke, u)), mul4(c.ke, v));
+            m.kd = add4(add4(mul4(a.kd, w), mul4(b.kd, u)), mul4(c.kd, v));
+            m.kr = add4(add4(mul4(a.kr, w), mul4(b.kr, u)), mul4(c.kr, v));
+            m.kt = add4(add4(mul4(a.kt, w), mul4(b.kt, u)), mul4(c.kt, v));
+            m.index = a.index * w + b.index * u + c.index * v;
+        } else {
+            m = load_mat(sc, mid[0]);
+        }
+    }
+}
+
+// CpuTracer.cu:37-53
+__device__ __forceinline__ f3 hemisphere(f3 N, float u1, float u2) {
+    f3 a = __builtin_fabsf(N.x) > MI_EPS ? normalize3(cross3(mk3(0, 1, 0), N)) : normalize3(cross3(mk3(1, 0, 0), N));
+    f3 b = cross3(N, a);
+    float p = 2 * 3.141592f * u1;
+    float sin_p, cos_p;
+    sincos_poly(p, sin_p, cos_p);
+    float cos_t = u2 * u2; // std::pow(u, 2) in double then rounded to float == RN(u*u)
+    float sin_t = __builtin_sqrtf(1.0f - cos_t * cos_t);
+    return sin_t * cos_p * a + sin_t * sin_p * b + cos_t * N;
+}
+
+// The reference evaluates radiance by recursion: value_k = ke_k*32 + w_k (.) value_{k+1}
+// (CpuTracer.cu:152,166,174,185).  To round exactly like it, every level stores
+// (e_k, w_k) and the terminating thread folds them from the deepest level back.
+__device__ __forceinline__ float4 fold_history(const float4 *hist_e, const float4 *hist_w, size_t cap, uint32_t slot, int levels, float4 val) {
+    for (int j = levels - 1; j >= 0; j--) {
+        float4 e = hist_e[(size_t)j * cap + slot], w = hist_w[(size_t)j * cap + slot];
+        val = add4(e, mul4(w, val));
+    }
+    return val;
+}
+__device__ __forceinline__ float4 clamp01_4(float4 a) { // vec.h:184-186, CpuTracer.cu:115
+    return make_float4(fminf(fmaxf(a.x, 0.0f), 1.0f), fminf(fmaxf(a.y, 0.0f), 1.0f), fminf(fmaxf(a.z, 0.0f), 1.0f),
+                       fminf(fmaxf(a.w, 0.0f), 1.0f));
+}
+
+// One thread per queue entry of level `level`; depth_left = D - level.
+__global__ void __launch_bounds__(MI_BLOCK)
+k_shade(DevScene sc, ShardGeom g, int64_t pix0, int32_t npix, int level, int depth_left, uint64_t seed,
+        const uint32_t *queue, const uint32_t *count_ptr, float4 *ray_o, float4 *ray_d, float4 *thr, const float4 *hits,
+        float4 *hist_e, float4 *hist_w, size_t cap, float4 *path_out, uint32_t *next_queue, uint32_t *next_count) {
+    const uint32_t n = *count_ptr;
+    const uint32_t stride = gridDim.x * MI_BLOCK;
+    // every lane of a wave runs the same number of iterations (queue_append uses wave-wide ops)
+    const uint32_t n_round = (n + 63u) & ~63u;
+    for (uint32_t i = blockIdx.x * MI_BLOCK + threadIdx.x; i < n_round; i += stride) {
+        bool alive = false;
+        uint32_t slot = 0;
+        if (i < n) {
+            slot = queue[i];
+            float4 h4 = hits[slot];
+            float t = h4.x;
+            int pslot = __float_as_int(h4.y);
+            float4 T = thr[slot];
+            if (pslot < 0) { // CpuTracer.cu:124-125: miss -> (1,1,1,1)
+                path_out[slot] = clamp01_4(fold_history(hist_e, hist_w, cap, slot, level, make_float4(1.0f, 1.0f, 1.0f, 1.0f)));
+            } else {
+                f3 o = xyz(ray_o[slot]), d = xyz(ray_d[slot]);
+                f3 N;
+                DMat m;
+                hit_surface(sc, pslot, t, h4.z, h4.w, o, d, N, m);
+                float4 e = mul4(m.ke, 32.0f); // CpuTracer.cu:131,185
+                if (depth_left < 0) {         // CpuTracer.cu:130-131
+                    path_out[slot] = clamp01_4(fold_history(hist_e, hist_w, cap, slot, level, e));
+                } else {
+                    f3 hitInner = o + (t + MI_EPS) * d; // :127
+                    f3 hitOuter = o + (t - MI_EPS) * d; // :128
+                    float reflect = m.kr.x, refract = m.kt.x; // :136-137
+                    // path id = (j*W + i)*spp + sx*s + sy, the oracle's key
+                    int samp = (int)(slot / (uint32_t)npix);
+                    int lp = (int)(slot - (uint32_t)samp * (uint32_t)npix);
+                    int px, py;
+                    local_to_pixel(g, slot_to_local(g, pix0 + lp), px, py);
+                    uint64_t path = ((uint64_t)py * g.width + px) * (uint64_t)(g.samples * g.samples) + (uint64_t)samp;
+                    uint32_t ctr[4] = {(uint32_t)path, (uint32_t)(path >> 32), (uint32_t)level, 0u};
+                    philox4x32_10(ctr, (uint32_t)seed, (uint32_t)(seed >> 32));
+                    float rnd = u01(ctr[0]); // :138
+                    f3 refl = d - (2.0f * N) * dot3(N, d); // :140
+                    f3 no, nd;
+                    float4 w;
+                    if (rnd < refract) { // :141
+                        bool into = dot3(d, N) < 0; // :142
+                        f3 nn = into ? N : -N;
+                        float n1 = 1.0f, n2 = m.index;
+                        float ratio = into ? n1 / n2 : n2 / n1;
+                        float dt = dot3(d, nn);
+                        float cos2t = 1 - ratio * ratio * (1 - dt * dt); // :148
+                        if (cos2t < 0) { // :149-152 total internal reflection
+                            no = hitOuter; nd = refl; w = m.kr;
+                        } else { // :154-166
+                            nd = normalize3(d * ratio - nn * (dt * ratio + __builtin_sqrtf(cos2t)));
+                            no = hitInner;
+                            float a = n2 - n1, b = n2 + n1;
+                            float R0 = (a * a) / (b * b);
+                            float cc = 1.0f - (into ? -dt : dot3(nd, -nn));
+                            float Re = R0 + (1.0f - R0) * cc * cc * cc * cc * cc;
+                            float ratio2 = ratio * ratio;
+                            float Tr = (1.0f - Re) * ratio2;
+                            w = make_float4(Tr, Tr, Tr, Tr);
+                        }
+                    } else { // :168-174 glossy/diffuse bounce
+                        f3 diff = hemisphere(N, u01(ctr[1]), u01(ctr[2]));
+                        nd = normalize3(reflect * refl + (1 - reflect) * diff);
+                        no = hitOuter; w = m.kd;
+                    }
+                    float4 Tn = mul4(w, T); // `w * thresh`, :152,166,174
+                    hist_e[(size_t)level * cap + slot] = e;
+                    hist_w[(size_t)level * cap + slot] = w;
+                    // entry test of the next level, CpuTracer.cu:121-122
+                    if ((double)length2_4(Tn) < 3.0 * 12.0 / 255.0 / 255.0) {
+                        path_out[slot] = clamp01_4(fold_history(hist_e, hist_w, cap, slot, level + 1, make_float4(0.0f, 0.0f, 0.0f, 0.0f)));
+                    } else {
+                        ray_o[slot] = make_float4(no.x, no.y, no.z, 0.0f);
+                        ray_d[slot] = make_float4(nd.x, nd.y, nd.z, 0.0f);
+                        thr[slot] = Tn;
+                        alive = true;
+                    }
+                }
+            }
+        }
+        queue_append(alive, slot, next_queue, next_count);
+    }
+}
+
+// ------------------------------------------------------------------ resolve
+__device__ __forceinline__ double hable(double x) { // tracer.cu:22-30
+    double a = 0.15, b = 0.50, c = 0.10, d = 0.20, e = 0.02, f = 0.30;
+    return ((x * (a * x + c * b) + d * e) / (x * (a * x + b) + d * f)) - e / f;
+}
+__device__ __forceinline__ uint8_t tonemap_byte(float c) { // tracer.cu:97
+    return (uint8_t)(int)(255.0 * (1.0 / hable(2.0)) * hable(2.0 * (double)c));
+}
+
+// One thread per local pixel of the batch, in OUTPUT order (row-major in tile):
+// mean over samples in the reference's order (sx outer, sy inner, CpuTracer.cu:101-108).
+__global__ void __launch_bounds__(MI_BLOCK)
+k_resolve(ShardGeom g, int64_t pix0, int32_t npix, const float4 *path_out, float4 *mean_out, uchar4 *rgba8_out) {
+    int lp = blockIdx.x * MI_BLOCK + threadIdx.x;
+    if (lp >= npix) return;
+    int spp = g.samples * g.samples;
+    int64_t q = slot_to_local(g, pix0 + lp); // the local pixel this batch position rendered
+    float4 sum = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    for (int s = 0; s < spp; s++) sum = add4(sum, path_out[(size_t)s * npix + lp]);
+    float div = (float)g.samples * g.samples; // CpuTracer.cu:108
+    float4 mean = make_float4(sum.x / div, sum.y / div, sum.z / div, sum.w / div);
+    if (mean_out) mean_out[q] = mean;
+    if (rgba8_out) {
+        int px, py;
+        bool inside = local_to_pixel(g, q, px, py);
+        rgba8_out[q] = inside ? make_uchar4(tonemap_byte(mean.x), tonemap_byte(mean.y), tonemap_byte(mean.z), 255)
+                              : make_uchar4(0, 0, 0, 0);
+    }
+}
+
+// Probe output for mi_trace_primary / mi_trace_rays.
+__global__ void __launch_bounds__(MI_BLOCK)
+k_probe_out(DevScene sc, int64_t n, const float4 *ray_o, const float4 *ray_d, const float4 *hits, int32_t *prim_id, float *t_out, float *n_out) {
+    int64_t i = (int64_t)blockIdx.x * MI_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    float4 h = hits[i];
+    int slot = __float_as_int(h.y);
+    prim_id[i] = slot < 0 ? -1 : sc.prim_id[slot];
+    t_out[i] = h.x;
+    if (n_out) {
+        f3 N = mk3(0, 0, 0);
+        if (slot >= 0) {
+            DMat m;
+            hit_surface(sc, slot, h.x, h.z, h.w, xyz(ray_o[i]), xyz(ray_d[i]), N, m);
+        }
+        n_out[3 * i] = N.x; n_out[3 * i + 1] = N.y; n_out[3 * i + 2] = N.z;
+    }
+}
+
+// Gathered shard-local RGBA8 -> bottom-up RGB8 frame (tracer.cu:96 layout).
+__global__ void __launch_bounds__(MI_BLOCK)
+k_assemble(ShardGeom g, const uchar4 *gathered, int64_t shard_stride, int64_t shard_pixels, uint8_t *rgb8) {
+    int64_t i = (int64_t)blockIdx.x * MI_BLOCK + threadIdx.x;
+    if (i >= shard_pixels * g.count) return;
+    int r = (int)(i / shard_pixels);
+    int64_t q = i - (int64_t)r * shard_pixels;
+    ShardGeom gr = g;
+    gr.rank = r;
+    int px, py;
+    if (!local_to_pixel(gr, q, px, py)) return;
+    uchar4 c = gathered[(size_t)r * shard_stride + q];
+    size_t o = ((size_t)px + (size_t)py * g.width) * 3;
+    rgb8[o] = c.x; rgb8[o + 1] = c.y; rgb8[o + 2] = c.z;
+}

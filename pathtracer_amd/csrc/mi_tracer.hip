@@ -1,0 +1,478 @@
+// mi_tracer.hip — C-ABI of include/mi_tracer.h: context, scene upload, wavefront
+// render loop.  Every hip* call is checked; errors are returned as status codes
+// with a thread-local message (the reference checks nothing, GpuTracer.cu:161-189).
+#include "mi_kernels.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mi_tracer.h"
+
+#define MI_API extern "C" __attribute__((visibility("default")))
+
+static thread_local std::string g_err;
+static mi_status fail(mi_status st, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return st;
+}
+#define HIPCHK(call)                                                                                       \
+    do {                                                                                                   \
+        hipError_t e_ = (call);                                                                            \
+        if (e_ != hipSuccess)                                                                              \
+            return fail(e_ == hipErrorOutOfMemory ? MI_ERR_OOM : MI_ERR_HIP, "%s failed: %s (%s:%d)", #call, \
+                        hipGetErrorString(e_), __FILE__, __LINE__);                                        \
+    } while (0)
+
+namespace {
+
+// Grow-only device buffer.
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    hipError_t ensure(size_t need) {
+        if (need <= bytes) return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); if (e != hipSuccess) return e; p = nullptr; bytes = 0; }
+        hipError_t e = hipMalloc(&p, need);
+        if (e == hipSuccess) bytes = need;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+    template <class T> T *as() const { return (T *)p; }
+};
+
+} // namespace
+
+struct mi_ctx {
+    int device = 0;
+    int n_cu = 256;
+    hipStream_t stream = nullptr;
+    bool has_scene = false;
+    DevScene sc{};
+    uint32_t n_nodes = 0;
+    DevBuf nodes, tri, tri_normal, tri_mat, tri_has_vmat, sph, sph_mat, mats, prim_id;
+    // per-batch path state (sized by slot capacity / depth)
+    DevBuf ray_o, ray_d, thr, hits, path_out, hist_e, hist_w, queue_a, queue_b, counters, ovf, totals;
+    // outputs for the host-pointer entry points
+    DevBuf out_mean, out_rgba8, out_rgb8, probe_i, probe_t, probe_n;
+    std::vector<hipEvent_t> ev;
+    uint64_t *h_totals = nullptr; // pinned
+};
+
+static const int kMaxLevels = 64; // counters reserved per batch (depth + 2 must fit)
+
+static int extend_grid(const mi_ctx *c) { return c->n_cu * 4; } // 4 workgroups x 4 waves per CU
+
+MI_API int mi_abi_version(void) { return 1; }
+MI_API const char *mi_last_error(void) { return g_err.c_str(); }
+
+MI_API mi_status mi_ctx_create(int device_id, mi_ctx **out) {
+    if (!out) return fail(MI_ERR_INVALID, "mi_ctx_create: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(MI_ERR_NO_DEVICE, "no HIP device available (%s)", e == hipSuccess ? "count is 0" : hipGetErrorString(e));
+    if (device_id < 0 || device_id >= n) return fail(MI_ERR_NO_DEVICE, "device %d out of range (0..%d)", device_id, n - 1);
+    HIPCHK(hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device_id));
+    mi_ctx *c = new mi_ctx;
+    c->device = device_id;
+    c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    hipError_t es = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (es != hipSuccess) { delete c; return fail(MI_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(es)); }
+    es = hipHostMalloc((void **)&c->h_totals, 4 * sizeof(uint64_t), hipHostMallocDefault);
+    if (es != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return fail(MI_ERR_HIP, "hipHostMalloc failed: %s", hipGetErrorString(es)); }
+    *out = c;
+    return MI_OK;
+}
+
+MI_API void mi_ctx_destroy(mi_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    DevBuf *all[] = {&c->nodes, &c->tri, &c->tri_normal, &c->tri_mat, &c->tri_has_vmat, &c->sph, &c->sph_mat, &c->mats,
+                     &c->prim_id, &c->ray_o, &c->ray_d, &c->thr, &c->hits, &c->path_out, &c->hist_e, &c->hist_w,
+                     &c->queue_a, &c->queue_b, &c->counters, &c->ovf, &c->totals, &c->out_mean, &c->out_rgba8,
+                     &c->out_rgb8, &c->probe_i, &c->probe_t, &c->probe_n};
+    for (DevBuf *b : all) b->release();
+    for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
+    if (c->h_totals) (void)hipHostFree(c->h_totals);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+// Host-side validation of the flattened BVH before any kernel may walk it: refs in
+// range, every primitive slot referenced exactly once, depth <= MI_MAX_STACK.
+static mi_status validate_scene(const mi_scene_soa *s) {
+    const uint64_t n_prim = (uint64_t)s->n_tri + s->n_sph;
+    if (n_prim == 0) return MI_OK;
+    if (!s->prim_id || !s->materials || s->n_mat == 0) return fail(MI_ERR_INVALID, "scene: prim_id/materials missing");
+    if (s->n_tri && !(s->tri_v0 && s->tri_uinv && s->tri_vinv && s->tri_ninv && s->tri_normal && s->tri_mat && s->tri_has_vmat))
+        return fail(MI_ERR_INVALID, "scene: triangle arrays missing");
+    if (s->n_sph && !(s->sph_center_radius && s->sph_mat)) return fail(MI_ERR_INVALID, "scene: sphere arrays missing");
+    for (uint64_t i = 0; i < 3ull * s->n_tri; i++)
+        if (s->tri_mat[i] >= s->n_mat) return fail(MI_ERR_INVALID, "scene: triangle material id out of range");
+    for (uint32_t i = 0; i < s->n_sph; i++)
+        if (s->sph_mat[i] >= s->n_mat) return fail(MI_ERR_INVALID, "scene: sphere material id out of range");
+    if (n_prim == 1) {
+        if (s->root_ref != ~0) return fail(MI_ERR_INVALID, "scene: one primitive needs root_ref == ~0");
+        return MI_OK;
+    }
+    if (s->n_nodes != n_prim - 1 || !s->nodes) return fail(MI_ERR_INVALID, "scene: %u nodes for %llu primitives (want n-1)", s->n_nodes, (unsigned long long)n_prim);
+    if (s->root_ref < 0 || (uint32_t)s->root_ref >= s->n_nodes) return fail(MI_ERR_INVALID, "scene: bad root_ref");
+    std::vector<uint8_t> seen_prim(n_prim, 0), seen_node(s->n_nodes, 0);
+    std::vector<std::pair<int32_t, int>> st;
+    st.push_back({s->root_ref, 1});
+    while (!st.empty()) {
+        auto [ref, depth] = st.back();
+        st.pop_back();
+        if (depth > MI_MAX_STACK) return fail(MI_ERR_INVALID, "scene: BVH deeper than %d", MI_MAX_STACK);
+        if (seen_node[ref]++) return fail(MI_ERR_INVALID, "scene: node %d referenced twice", ref);
+        for (int c = 0; c < 2; c++) {
+            int32_t ch;
+            memcpy(&ch, s->nodes + 16 * (size_t)ref + 12 + c, 4);
+            if (ch < 0) {
+                uint32_t slot = (uint32_t)~ch;
+                if (slot >= n_prim) return fail(MI_ERR_INVALID, "scene: leaf slot out of range");
+                if (seen_prim[slot]++) return fail(MI_ERR_INVALID, "scene: primitive slot %u referenced twice", slot);
+            } else {
+                if ((uint32_t)ch >= s->n_nodes) return fail(MI_ERR_INVALID, "scene: child node out of range");
+                st.push_back({ch, depth + 1});
+            }
+        }
+    }
+    return MI_OK;
+}
+
+MI_API mi_status mi_scene_upload(mi_ctx *c, const mi_scene_soa *s) {
+    if (!c || !s) return fail(MI_ERR_INVALID, "mi_scene_upload: NULL argument");
+    mi_status vs = validate_scene(s);
+    if (vs != MI_OK) return vs;
+    HIPCHK(hipSetDevice(c->device));
+    c->has_scene = false;
+    const size_t nt = s->n_tri, ns = s->n_sph;
+    auto up = [&](DevBuf &b, const void *src, size_t bytes) -> hipError_t {
+        hipError_t e = b.ensure(std::max<size_t>(bytes, 16));
+        if (e != hipSuccess || bytes == 0) return e;
+        return hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice);
+    };
+    HIPCHK(up(c->nodes, s->nodes, (size_t)s->n_nodes * 64));
+    // interleave v0,uInv,vInv,nInv into one 64-B record per triangle
+    std::vector<float> rec(16 * nt);
+    for (size_t i = 0; i < nt; i++) {
+        memcpy(&rec[16 * i + 0], s->tri_v0 + 4 * i, 16);
+        memcpy(&rec[16 * i + 4], s->tri_uinv + 4 * i, 16);
+        memcpy(&rec[16 * i + 8], s->tri_vinv + 4 * i, 16);
+        memcpy(&rec[16 * i + 12], s->tri_ninv + 4 * i, 16);
+    }
+    HIPCHK(up(c->tri, rec.data(), nt * 64));
+    HIPCHK(up(c->tri_normal, s->tri_normal, nt * 16));
+    HIPCHK(up(c->tri_mat, s->tri_mat, nt * 12));
+    HIPCHK(up(c->tri_has_vmat, s->tri_has_vmat, nt));
+    HIPCHK(up(c->sph, s->sph_center_radius, ns * 16));
+    HIPCHK(up(c->sph_mat, s->sph_mat, ns * 4));
+    HIPCHK(up(c->mats, s->materials, (size_t)s->n_mat * 80));
+    HIPCHK(up(c->prim_id, s->prim_id, (nt + ns) * 4));
+    DevScene &d = c->sc;
+    d.nodes = c->nodes.as<float4>();
+    d.tri = c->tri.as<float4>();
+    d.tri_normal = c->tri_normal.as<float4>();
+    d.tri_mat = c->tri_mat.as<uint32_t>();
+    d.tri_has_vmat = c->tri_has_vmat.as<uint8_t>();
+    d.sph = c->sph.as<float4>();
+    d.sph_mat = c->sph_mat.as<uint32_t>();
+    d.mats = c->mats.as<float4>();
+    d.prim_id = c->prim_id.as<int32_t>();
+    d.root_ref = s->root_ref;
+    d.n_tri = s->n_tri;
+    d.n_sph = s->n_sph;
+    d.eye = make_float4(s->cam_eye[0], s->cam_eye[1], s->cam_eye[2], s->cam_eye[3]);
+    d.u = make_float4(s->cam_u[0], s->cam_u[1], s->cam_u[2], s->cam_u[3]);
+    d.v = make_float4(s->cam_v[0], s->cam_v[1], s->cam_v[2], s->cam_v[3]);
+    d.look = make_float4(s->cam_look[0], s->cam_look[1], s->cam_look[2], s->cam_look[3]);
+    c->n_nodes = s->n_nodes;
+    c->has_scene = true;
+    return MI_OK;
+}
+
+static mi_status make_geom(const mi_render_params *p, ShardGeom &g) {
+    if (!p) return fail(MI_ERR_INVALID, "params is NULL");
+    if (p->width <= 0 || p->height <= 0 || p->samples_per_dim <= 0 || p->samples_per_dim > 1024)
+        return fail(MI_ERR_INVALID, "bad image size or sample count");
+    if (p->depth < -1 || p->depth + 2 > kMaxLevels) return fail(MI_ERR_INVALID, "depth %d out of range", p->depth);
+    g.width = p->width; g.height = p->height;
+    g.tile_w = p->tile_w > 0 ? p->tile_w : 32;
+    g.tile_h = p->tile_h > 0 ? p->tile_h : 32;
+    g.tiles_x = (g.width + g.tile_w - 1) / g.tile_w;
+    int tiles_y = (g.height + g.tile_h - 1) / g.tile_h;
+    int64_t nt = (int64_t)g.tiles_x * tiles_y;
+    if (nt > INT32_MAX) return fail(MI_ERR_INVALID, "too many tiles");
+    g.n_tiles = (int32_t)nt;
+    g.count = p->shard_count > 1 ? p->shard_count : 1;
+    g.rank = p->shard_count > 1 ? p->shard_rank : 0;
+    if (g.rank < 0 || g.rank >= g.count) return fail(MI_ERR_INVALID, "shard_rank %d not in [0,%d)", g.rank, g.count);
+    g.samples = p->samples_per_dim;
+    return MI_OK;
+}
+
+static int64_t shard_pixels(const ShardGeom &g) {
+    int64_t owned = g.rank < g.n_tiles ? ((int64_t)g.n_tiles - g.rank + g.count - 1) / g.count : 0;
+    return owned * g.tile_w * g.tile_h;
+}
+
+MI_API int64_t mi_shard_pixels(const mi_render_params *p) {
+    ShardGeom g;
+    if (make_geom(p, g) != MI_OK) return -1;
+    return shard_pixels(g);
+}
+
+static mi_status get_events(mi_ctx *c, size_t n) {
+    while (c->ev.size() < n) {
+        hipEvent_t e;
+        HIPCHK(hipEventCreate(&e));
+        c->ev.push_back(e);
+    }
+    return MI_OK;
+}
+
+__global__ void k_sum_counts(const uint32_t *counts, int n, uint64_t *totals) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        uint64_t s = 0;
+        for (int i = 0; i < n; i++) s += counts[i];
+        totals[0] += s;         // rays cast = sum of extend queue lengths
+        totals[1] += counts[0]; // paths started
+    }
+}
+
+MI_API mi_status mi_render_device(mi_ctx *c, const mi_render_params *p, void *d_rgba_mean, void *d_rgba8, void *stream_v,
+                                  mi_stats *stats) {
+    if (!c) return fail(MI_ERR_INVALID, "ctx is NULL");
+    if (!c->has_scene) return fail(MI_ERR_NO_SCENE, "mi_render: no scene uploaded");
+    ShardGeom g;
+    mi_status gs = make_geom(p, g);
+    if (gs != MI_OK) return gs;
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t st = stream_v ? (hipStream_t)stream_v : c->stream;
+    const int64_t local = shard_pixels(g);
+    const int spp = g.samples * g.samples;
+    const int levels = p->depth + 2; // rays per path <= D+2 (CpuTracer.cu:119-131)
+    int64_t want = p->batch_paths > 0 ? p->batch_paths : (int64_t)8 << 20;
+    want = std::min<int64_t>(want, (int64_t)1 << 30);
+    int64_t npix_b = std::max<int64_t>(64, want / spp / 64 * 64);
+    npix_b = std::min(npix_b, std::max<int64_t>(local, 1));
+    const int64_t cap64 = npix_b * spp;
+    if (cap64 >= ((int64_t)1 << 32) - 64) return fail(MI_ERR_INVALID, "batch too large (samples_per_dim too high)");
+    const size_t cap = (size_t)cap64;
+    const int hist_levels = std::max(1, p->depth + 1);
+    HIPCHK(c->ray_o.ensure(cap * 16));
+    HIPCHK(c->ray_d.ensure(cap * 16));
+    HIPCHK(c->thr.ensure(cap * 16));
+    HIPCHK(c->hits.ensure(cap * 16));
+    HIPCHK(c->path_out.ensure(cap * 16));
+    HIPCHK(c->hist_e.ensure(cap * 16 * hist_levels));
+    HIPCHK(c->hist_w.ensure(cap * 16 * hist_levels));
+    HIPCHK(c->queue_a.ensure(cap * 4));
+    HIPCHK(c->queue_b.ensure(cap * 4));
+    HIPCHK(c->counters.ensure(2 * (kMaxLevels + 1) * 4));
+    const int egrid = extend_grid(c);
+    HIPCHK(c->ovf.ensure((size_t)(MI_MAX_STACK - MI_LDS_STACK) * egrid * MI_BLOCK * 4));
+    HIPCHK(c->totals.ensure(4 * 8));
+    const int64_t n_batches = local > 0 ? (local + npix_b - 1) / npix_b : 0;
+    const size_t n_ev = 2 + (size_t)n_batches * levels * 3;
+    const bool per_launch = n_ev <= 4096; // per-launch timing only while the event count stays modest
+    mi_status es = get_events(c, per_launch ? n_ev : 2);
+    if (es != MI_OK) return es;
+
+    uint32_t *cnt = c->counters.as<uint32_t>();          // cnt[k] = queue length at level k
+    uint32_t *cur = cnt + (kMaxLevels + 1);              // cur[k] = work cursor of extend at level k
+    uint32_t *qa = c->queue_a.as<uint32_t>(), *qb = c->queue_b.as<uint32_t>();
+    HIPCHK(hipMemsetAsync(c->totals.p, 0, 32, st));
+    HIPCHK(hipEventRecord(c->ev[0], st));
+    size_t evi = 2;
+    const int sgrid = std::min<int64_t>((int64_t)c->n_cu * 8, (cap + MI_BLOCK - 1) / MI_BLOCK);
+    for (int64_t b = 0; b < n_batches; b++) {
+        const int64_t pix0 = b * npix_b;
+        const int32_t np = (int32_t)std::min<int64_t>(npix_b, local - pix0);
+        const int64_t nslots = (int64_t)np * spp;
+        HIPCHK(hipMemsetAsync(cnt, 0, 2 * (kMaxLevels + 1) * 4, st));
+        hipLaunchKernelGGL(k_generate, dim3((unsigned)((nslots + MI_BLOCK - 1) / MI_BLOCK)), dim3(MI_BLOCK), 0, st, c->sc, g, pix0, np,
+                           c->ray_o.as<float4>(), c->ray_d.as<float4>(), c->thr.as<float4>(), c->path_out.as<float4>(), qa, cnt);
+        for (int k = 0; k < levels; k++) {
+            uint32_t *qin = (k & 1) ? qb : qa, *qout = (k & 1) ? qa : qb;
+            if (per_launch) HIPCHK(hipEventRecord(c->ev[evi++], st));
+            hipLaunchKernelGGL(k_extend, dim3(egrid), dim3(MI_BLOCK), 0, st, c->sc, qin, cnt + k, 0u, cur + k, c->ray_o.as<float4>(),
+                               c->ray_d.as<float4>(), c->hits.as<float4>(), c->ovf.as<int>());
+            if (per_launch) HIPCHK(hipEventRecord(c->ev[evi++], st));
+            hipLaunchKernelGGL(k_shade, dim3(sgrid), dim3(MI_BLOCK), 0, st, c->sc, g, pix0, np, k, p->depth - k, p->seed, qin, cnt + k,
+                               c->ray_o.as<float4>(), c->ray_d.as<float4>(), c->thr.as<float4>(), c->hits.as<float4>(),
+                               c->hist_e.as<float4>(), c->hist_w.as<float4>(), cap, c->path_out.as<float4>(), qout, cnt + k + 1);
+            if (per_launch) HIPCHK(hipEventRecord(c->ev[evi++], st));
+        }
+        hipLaunchKernelGGL(k_resolve, dim3((np + MI_BLOCK - 1) / MI_BLOCK), dim3(MI_BLOCK), 0, st, g, pix0, np, c->path_out.as<float4>(),
+                           (float4 *)d_rgba_mean, (uchar4 *)d_rgba8);
+        hipLaunchKernelGGL(k_sum_counts, dim3(1), dim3(64), 0, st, cnt, levels, c->totals.as<uint64_t>());
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(c->h_totals, c->totals.p, 32, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipEventRecord(c->ev[1], st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (stats) {
+        memset(stats, 0, sizeof *stats);
+        stats->rays_cast = c->h_totals[0];
+        stats->paths = c->h_totals[1];
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+        stats->ms_total = ms;
+        stats->batches = (uint32_t)n_batches;
+        if (per_launch) {
+            double me = 0, msh = 0;
+            for (size_t i = 2; i + 3 <= evi; i += 3) {
+                float a = 0, b2 = 0;
+                HIPCHK(hipEventElapsedTime(&a, c->ev[i], c->ev[i + 1]));
+                HIPCHK(hipEventElapsedTime(&b2, c->ev[i + 1], c->ev[i + 2]));
+                me += a; msh += b2;
+                stats->extend_launches++;
+            }
+            stats->ms_extend = me;
+            stats->ms_shade = msh;
+            stats->ms_other = std::max(0.0, stats->ms_total - me - msh);
+        }
+    }
+    return MI_OK;
+}
+
+MI_API mi_status mi_render(mi_ctx *c, const mi_render_params *p, float *rgba_mean_out, uint8_t *rgb8_out, mi_stats *stats) {
+    if (!c) return fail(MI_ERR_INVALID, "ctx is NULL");
+    if (!c->has_scene) return fail(MI_ERR_NO_SCENE, "mi_render: no scene uploaded");
+    ShardGeom g;
+    mi_status gs = make_geom(p, g);
+    if (gs != MI_OK) return gs;
+    HIPCHK(hipSetDevice(c->device));
+    const int64_t local = shard_pixels(g);
+    HIPCHK(c->out_mean.ensure(std::max<size_t>((size_t)local * 16, 16)));
+    HIPCHK(c->out_rgba8.ensure(std::max<size_t>((size_t)local * 4, 16)));
+    mi_status rs = mi_render_device(c, p, rgba_mean_out ? c->out_mean.p : nullptr, rgb8_out ? c->out_rgba8.p : nullptr, nullptr, stats);
+    if (rs != MI_OK) return rs;
+    // un-permute shard-local order into the caller's full-frame buffers
+    std::vector<float> mean;
+    std::vector<uint8_t> rgba;
+    if (rgba_mean_out) { mean.resize((size_t)local * 4); HIPCHK(hipMemcpy(mean.data(), c->out_mean.p, (size_t)local * 16, hipMemcpyDeviceToHost)); }
+    if (rgb8_out) { rgba.resize((size_t)local * 4); HIPCHK(hipMemcpy(rgba.data(), c->out_rgba8.p, (size_t)local * 4, hipMemcpyDeviceToHost)); }
+    const int tpix = g.tile_w * g.tile_h;
+    for (int64_t q = 0; q < local; q++) {
+        int64_t j = q / tpix;
+        int off = (int)(q - j * tpix);
+        int64_t gt = g.rank + j * (int64_t)g.count;
+        int px = (int)(gt % g.tiles_x) * g.tile_w + off % g.tile_w, py = (int)(gt / g.tiles_x) * g.tile_h + off / g.tile_w;
+        if (px >= g.width || py >= g.height) continue;
+        size_t o = (size_t)px + (size_t)py * g.width;
+        if (rgba_mean_out) memcpy(rgba_mean_out + 4 * o, &mean[4 * (size_t)q], 16);
+        if (rgb8_out) { rgb8_out[3 * o] = rgba[4 * (size_t)q]; rgb8_out[3 * o + 1] = rgba[4 * (size_t)q + 1]; rgb8_out[3 * o + 2] = rgba[4 * (size_t)q + 2]; }
+    }
+    return MI_OK;
+}
+
+MI_API mi_status mi_assemble_rgb8(mi_ctx *c, const mi_render_params *p, const void *d_gathered, int64_t shard_stride_pixels, uint8_t *rgb8_out) {
+    if (!c || !d_gathered || !rgb8_out) return fail(MI_ERR_INVALID, "mi_assemble_rgb8: NULL argument");
+    ShardGeom g;
+    mi_status gs = make_geom(p, g);
+    if (gs != MI_OK) return gs;
+    HIPCHK(hipSetDevice(c->device));
+    ShardGeom g0 = g;
+    g0.rank = 0;
+    const int64_t sp = shard_pixels(g0); // rank 0 owns the most tiles
+    if (shard_stride_pixels < sp) return fail(MI_ERR_INVALID, "shard stride %lld < shard pixels %lld", (long long)shard_stride_pixels, (long long)sp);
+    const size_t bytes = (size_t)g.width * g.height * 3;
+    HIPCHK(c->out_rgb8.ensure(bytes));
+    HIPCHK(hipMemsetAsync(c->out_rgb8.p, 0, bytes, c->stream));
+    const int64_t total = sp * g.count;
+    hipLaunchKernelGGL(k_assemble, dim3((unsigned)((total + MI_BLOCK - 1) / MI_BLOCK)), dim3(MI_BLOCK), 0, c->stream, g, (const uchar4 *)d_gathered,
+                       shard_stride_pixels, sp, c->out_rgb8.as<uint8_t>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(rgb8_out, c->out_rgb8.p, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return MI_OK;
+}
+
+// Shared tail of the two probes: extend over n rays already in ray_o/ray_d, copy out.
+static mi_status probe_chunk(mi_ctx *c, int64_t n, int32_t *prim_id_out, float *t_out, float *n_out) {
+    hipStream_t st = c->stream;
+    uint32_t *cur = c->counters.as<uint32_t>();
+    HIPCHK(hipMemsetAsync(cur, 0, 4, st));
+    hipLaunchKernelGGL(k_extend, dim3(extend_grid(c)), dim3(MI_BLOCK), 0, st, c->sc, (const uint32_t *)nullptr, (const uint32_t *)nullptr,
+                       (uint32_t)n, cur, c->ray_o.as<float4>(), c->ray_d.as<float4>(), c->hits.as<float4>(), c->ovf.as<int>());
+    hipLaunchKernelGGL(k_probe_out, dim3((unsigned)((n + MI_BLOCK - 1) / MI_BLOCK)), dim3(MI_BLOCK), 0, st, c->sc, n, c->ray_o.as<float4>(),
+                       c->ray_d.as<float4>(), c->hits.as<float4>(), c->probe_i.as<int32_t>(), c->probe_t.as<float>(),
+                       n_out ? c->probe_n.as<float>() : nullptr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(prim_id_out, c->probe_i.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(t_out, c->probe_t.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    if (n_out) HIPCHK(hipMemcpyAsync(n_out, c->probe_n.p, (size_t)n * 12, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return MI_OK;
+}
+
+static mi_status probe_alloc(mi_ctx *c, size_t chunk) {
+    HIPCHK(c->ray_o.ensure(chunk * 16));
+    HIPCHK(c->ray_d.ensure(chunk * 16));
+    HIPCHK(c->hits.ensure(chunk * 16));
+    HIPCHK(c->probe_i.ensure(chunk * 4));
+    HIPCHK(c->probe_t.ensure(chunk * 4));
+    HIPCHK(c->probe_n.ensure(chunk * 12));
+    HIPCHK(c->counters.ensure(2 * (kMaxLevels + 1) * 4));
+    HIPCHK(c->ovf.ensure((size_t)(MI_MAX_STACK - MI_LDS_STACK) * extend_grid(c) * MI_BLOCK * 4));
+    return MI_OK;
+}
+
+MI_API mi_status mi_trace_primary(mi_ctx *c, int32_t width, int32_t height, int32_t samples, int32_t *prim_id_out, float *t_out, float *n_out) {
+    if (!c || !prim_id_out || !t_out) return fail(MI_ERR_INVALID, "mi_trace_primary: NULL argument");
+    if (!c->has_scene) return fail(MI_ERR_NO_SCENE, "mi_trace_primary: no scene uploaded");
+    if (width <= 0 || height <= 0 || samples <= 0 || samples > 1024) return fail(MI_ERR_INVALID, "bad image size or sample count");
+    HIPCHK(hipSetDevice(c->device));
+    const int64_t total = (int64_t)width * height * samples * samples;
+    const int64_t chunk = std::min<int64_t>(total, (int64_t)4 << 20);
+    mi_status as = probe_alloc(c, (size_t)chunk);
+    if (as != MI_OK) return as;
+    for (int64_t first = 0; first < total; first += chunk) {
+        int64_t n = std::min(chunk, total - first);
+        hipLaunchKernelGGL(k_generate_primary, dim3((unsigned)((n + MI_BLOCK - 1) / MI_BLOCK)), dim3(MI_BLOCK), 0, c->stream, c->sc, width, height,
+                           samples, first, n, c->ray_o.as<float4>(), c->ray_d.as<float4>());
+        mi_status ps = probe_chunk(c, n, prim_id_out + first, t_out + first, n_out ? n_out + 3 * first : nullptr);
+        if (ps != MI_OK) return ps;
+    }
+    return MI_OK;
+}
+
+MI_API mi_status mi_trace_rays(mi_ctx *c, int64_t total, const float *rays, int32_t *prim_id_out, float *t_out, float *n_out) {
+    if (!c || !rays || !prim_id_out || !t_out || total < 0) return fail(MI_ERR_INVALID, "mi_trace_rays: bad argument");
+    if (!c->has_scene) return fail(MI_ERR_NO_SCENE, "mi_trace_rays: no scene uploaded");
+    if (total == 0) return MI_OK;
+    HIPCHK(hipSetDevice(c->device));
+    const int64_t chunk = std::min<int64_t>(total, (int64_t)4 << 20);
+    mi_status as = probe_alloc(c, (size_t)chunk);
+    if (as != MI_OK) return as;
+    std::vector<float> o4((size_t)chunk * 4), d4((size_t)chunk * 4);
+    for (int64_t first = 0; first < total; first += chunk) {
+        int64_t n = std::min(chunk, total - first);
+        for (int64_t i = 0; i < n; i++) {
+            const float *r = rays + 6 * (first + i);
+            o4[4 * i] = r[0]; o4[4 * i + 1] = r[1]; o4[4 * i + 2] = r[2]; o4[4 * i + 3] = 0;
+            d4[4 * i] = r[3]; d4[4 * i + 1] = r[4]; d4[4 * i + 2] = r[5]; d4[4 * i + 3] = 0;
+        }
+        HIPCHK(hipMemcpyAsync(c->ray_o.p, o4.data(), (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->ray_d.p, d4.data(), (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
+        mi_status ps = probe_chunk(c, n, prim_id_out + first, t_out + first, n_out ? n_out + 3 * first : nullptr);
+        if (ps != MI_OK) return ps;
+    }
+    return MI_OK;
+}

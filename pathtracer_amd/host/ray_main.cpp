@@ -1,0 +1,60 @@
+// ray_main.cpp — the `ray` executable: same command line as the reference
+// (src/main.cu:7-14, src/ui/CommandLineUI.cu:21-101) with the MI355X backend as
+// the tracer.  getopt string "t:r:w:hj:c:s:gq:" is accepted unchanged; -g selects
+// the GPU backend in the reference and is implied here (the only backend), -q
+// (CUDA threads per block) is accepted and ignored, -j/-c are accepted and
+// ignored (JSON overrides and cubemaps are outside this backend's scope).
+// Added: -G <device>, -S <seed>.
+#include <unistd.h>
+
+#include <cmath>
+#include <cstdlib>
+#include <iostream>
+
+#include "tracer.h"
+
+int main(int argc, char **argv) {
+    pt::TraceOptions o;
+    int size = 512; // TraceUI.h:55
+    int c;
+    while ((c = getopt(argc, argv, "t:r:w:hj:c:s:gq:G:S:")) != -1) {
+        switch (c) {
+            case 't': o.threads = atoi(optarg); // falls through into -r, CommandLineUI.cu:29-33
+            case 'r': o.depth = atoi(optarg); break;
+            case 'w': size = atoi(optarg); break;
+            case 's': o.samples = atoi(optarg); break;
+            case 'G': o.device = atoi(optarg); break;
+            case 'S': o.seed = strtoull(optarg, nullptr, 10); break;
+            case 'j': case 'c': case 'q': case 'g': break;
+            default:
+                std::cerr << "usage: " << argv[0] << " [options] [input.ray output.png]\n"
+                          << "  -r <#>  recursion level (default 0)\n  -w <#>  image width (default 512)\n"
+                          << "  -s <#>  samples per dimension (default 2)\n  -G <#>  HIP device\n  -S <#>  RNG seed\n";
+                return 1;
+        }
+    }
+    if (optind >= argc - 1) { // CommandLineUI.cu:70-73
+        std::cerr << "no input and/or output name." << std::endl;
+        return 1;
+    }
+    const char *rayName = argv[optind], *imgName = argv[optind + 1];
+    pt::HipTracer tracer(o);
+    if (!tracer.ok()) return 2;
+    if (!tracer.loadScene(rayName)) { // CommandLineUI.cu:82,96-100
+        std::cerr << "Unable to load ray file '" << rayName << "'" << std::endl;
+        return 1;
+    }
+    int width = size;
+    int height = (int)std::round(width / tracer.aspectRatio() + 0.5); // CommandLineUI.cu:83-84
+    tracer.traceSetup(width, height);
+    tracer.traceImage(width, height);
+    tracer.waitRender();
+    if (!tracer.ok()) return 2;
+    unsigned char *buf;
+    tracer.getBuffer(buf, width, height);
+    if (buf) pt::writeImage(imgName, width, height, buf);
+    const mi_stats &st = tracer.stats();
+    std::cerr << width << "x" << height << " rays=" << st.rays_cast << " ms=" << st.ms_total << " Mrays/s="
+              << (st.ms_total > 0 ? st.rays_cast / st.ms_total / 1e3 : 0) << std::endl;
+    return 0;
+}

@@ -1,0 +1,83 @@
+// tracer.h — the Tracer interface of the reference (src/tracer.h:19-52) and the
+// MI355X backend that plugs in behind it.
+//
+// Same call sequence as CommandLineUI::run() drives (src/ui/CommandLineUI.cu:82-94):
+//   loadScene -> traceSetup -> traceImage -> waitRender -> getBuffer.
+// traceImage may return before the image is done; waitRender is the completion
+// point (CpuTracer spawns threads, src/CpuTracer.cu:57-97,188-191).
+#pragma once
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/mi_tracer.h"
+#include "scene.h"
+
+namespace pt {
+
+// The subset of TraceUI (src/ui/TraceUI.h:21-83) the tracers read
+// (src/tracer.h:21-25,56-59,80-82).
+struct TraceOptions {
+    int depth = 0;          // -r, TraceUI.h:56 default 0
+    int samples = 2;        // -s, per dimension, TraceUI.h:59 default 2
+    int threads = 0;        // -t (CPU backends only)
+    int device = 0;         // HIP device of the MI355X backend
+    unsigned long long seed = 0;
+};
+
+class Tracer {
+public:
+    explicit Tracer(const TraceOptions &o) : depth(o.depth), samples(o.samples) {}
+    virtual ~Tracer();
+
+    double aspectRatio();                         // tracer.cu:38-40
+    bool loadScene(const char *fn);               // tracer.cu:42-85 (errors -> stderr, false)
+    bool loadSceneText(const std::string &text);  // same, from memory
+    void traceSetup(int w, int h);                // tracer.cu:87-93
+    virtual void traceImage(int w, int h) = 0;    // tracer.h:35
+    virtual void waitRender() = 0;                // tracer.h:37
+    void getBuffer(unsigned char *&buf, int &w, int &h); // tracer.cu:32-36
+    Scene *getScene() { return scene; }
+
+protected:
+    virtual bool sceneLoaded() { return true; }
+    unsigned depth;
+    unsigned samples;
+    Scene *scene = nullptr;
+    std::vector<unsigned char> buffer;            // RGB8, row 0 = bottom row
+    int buffer_width = 0, buffer_height = 0;
+};
+
+// Third Tracer backend: hand-written HIP wavefront pipeline behind the C-ABI of
+// include/mi_tracer.h.  Takes the place of GpuTracer (src/tracer.h:78-90,
+// src/GpuTracer.cu:161-193).  Fails loudly (loadScene returns false / traceImage
+// reports on stderr and leaves the buffer zeroed) when no HIP device is present;
+// there is no CPU fallback.
+class HipTracer : public Tracer {
+public:
+    explicit HipTracer(const TraceOptions &o);
+    ~HipTracer() override;
+    void traceImage(int w, int h) override;
+    void waitRender() override;
+    const mi_stats &stats() const { return stats_; }
+    bool ok() const { return status_ == MI_OK; }
+    std::string error() const { return error_; }
+
+protected:
+    bool sceneLoaded() override;
+
+private:
+    TraceOptions opts_;
+    mi_ctx *ctx_ = nullptr;
+    std::thread worker_;
+    mi_stats stats_{};
+    mi_status status_ = MI_OK;
+    std::string error_;
+};
+
+// Image output (counterpart of src/fileio/images.cu:59-68): ".png" -> PNG RGB8,
+// anything else -> BMP; rows are flipped so that buffer row 0 is the bottom row
+// (src/fileio/pngimage.cu:258-268, src/fileio/bitmap.cu:95-149).
+bool writeImage(const char *path, int w, int h, const unsigned char *rgb);
+
+} // namespace pt

@@ -1,0 +1,125 @@
+"""Python mirror of the reference's Tracer interface for the MI355X backend.
+
+``HipTracer`` has the reference's method sequence (src/tracer.h:19-52, driven by
+src/ui/CommandLineUI.cu:82-94): ``load_scene -> trace_setup -> trace_image ->
+wait_render -> get_buffer``.  ``Context`` is the thin object over the raw C-ABI
+(``include/mi_tracer.h``) used by the parity tests and the bench.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _native as N
+from .scene import Scene
+
+
+class Context:
+    """One ``mi_ctx`` = one GPU."""
+
+    def __init__(self, device=0):
+        h = C.c_void_p()
+        N.check(N.mi.mi_ctx_create(device, C.byref(h)))
+        self._h = h
+        self.scene = None
+
+    def close(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            N.mi.mi_ctx_destroy(h)
+
+    __del__ = close
+
+    def upload(self, scene: Scene):
+        N.check(N.mi.mi_scene_upload(self._h, scene.soa))
+        self.scene = scene  # keep the host arrays alive (not required by the ABI)
+
+    @staticmethod
+    def params(width, height, samples, depth, seed=0, tile=(0, 0), shard=(0, 1), batch_paths=0):
+        return N.RenderParams(width, height, samples, depth, seed, tile[0], tile[1], shard[0], shard[1], batch_paths)
+
+    def render(self, params, want_mean=True, want_rgb8=True):
+        """Host-buffer render.  Returns (mean float32[h,w,4] | None, rgb8 uint8[h,w,3] | None, Stats);
+        row 0 is the bottom row (src/tracer.cu:96)."""
+        w, h = params.width, params.height
+        mean = np.zeros((h, w, 4), np.float32) if want_mean else None
+        rgb = np.zeros((h, w, 3), np.uint8) if want_rgb8 else None
+        st = N.Stats()
+        N.check(N.mi.mi_render(self._h, C.byref(params), mean.ctypes.data if want_mean else None,
+                               rgb.ctypes.data if want_rgb8 else None, C.byref(st)))
+        return mean, rgb, st
+
+    def render_device(self, params, d_mean_ptr, d_rgba8_ptr, stream=None):
+        st = N.Stats()
+        N.check(N.mi.mi_render_device(self._h, C.byref(params), d_mean_ptr, d_rgba8_ptr, stream, C.byref(st)))
+        return st
+
+    def assemble_rgb8(self, params, d_gathered_ptr, shard_stride_pixels):
+        rgb = np.zeros((params.height, params.width, 3), np.uint8)
+        N.check(N.mi.mi_assemble_rgb8(self._h, C.byref(params), d_gathered_ptr, shard_stride_pixels, rgb.ctypes.data))
+        return rgb
+
+    def trace_primary(self, width, height, samples, want_normals=True):
+        n = width * height * samples * samples
+        ids = np.empty(n, np.int32)
+        t = np.empty(n, np.float32)
+        nrm = np.empty((n, 3), np.float32) if want_normals else None
+        N.check(N.mi.mi_trace_primary(self._h, width, height, samples, ids.ctypes.data, t.ctypes.data,
+                                      nrm.ctypes.data if want_normals else None))
+        return ids, t, nrm
+
+    def trace_rays(self, rays, want_normals=True):
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
+        n = len(rays)
+        ids = np.empty(n, np.int32)
+        t = np.empty(n, np.float32)
+        nrm = np.empty((n, 3), np.float32) if want_normals else None
+        N.check(N.mi.mi_trace_rays(self._h, n, rays.ctypes.data, ids.ctypes.data, t.ctypes.data,
+                                   nrm.ctypes.data if want_normals else None))
+        return ids, t, nrm
+
+
+def shard_pixels(params):
+    return N.mi.mi_shard_pixels(C.byref(params))
+
+
+class HipTracer:
+    """The Tracer-shaped object (C++ class pt::HipTracer in pathtracer_amd/host/tracer.h)."""
+
+    def __init__(self, depth=0, samples=2, device=0, seed=0):
+        h = N.host.pt_hip_tracer_new(depth, samples, device, seed)
+        if not h:
+            raise N.MiError(N.MI_ERR_NO_DEVICE, N.host.pt_last_error().decode())
+        self._h = C.c_void_p(h)
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            N.host.pt_tracer_free(h)
+
+    def load_scene(self, path=None, text=None):
+        arg = (str(path).encode(), 1) if path is not None else (text.encode(), 0)
+        return bool(N.host.pt_tracer_load_scene(self._h, *arg))
+
+    def aspect_ratio(self):
+        return N.host.pt_tracer_aspect(self._h)
+
+    def trace_setup(self, w, h):
+        N.host.pt_tracer_trace_setup(self._h, w, h)
+
+    def trace_image(self, w, h):
+        N.host.pt_tracer_trace_image(self._h, w, h)
+
+    def wait_render(self):
+        if not N.host.pt_tracer_wait_render(self._h):
+            raise N.MiError(N.MI_ERR_HIP, N.host.pt_last_error().decode())
+
+    def get_buffer(self):
+        buf = C.POINTER(C.c_ubyte)()
+        w, h = C.c_int(), C.c_int()
+        N.host.pt_tracer_get_buffer(self._h, C.byref(buf), C.byref(w), C.byref(h))
+        return np.ctypeslib.as_array(buf, shape=(h.value, w.value, 3)).copy()
+
+    def stats(self):
+        st = N.Stats()
+        N.host.pt_tracer_stats(self._h, C.byref(st))
+        return st
