@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""bench.py — Mrays/s of the HIP wavefront path tracer on the BASELINE workload.
+
+A step = one full render of the workload image (every pixel, every sample, all
+bounces), inputs (flattened scene) already resident in HBM.  With N ranks the image
+is sharded by 32x32 tile (tile k -> rank k % N, BVH replicated); every rank renders
+its tiles and the tonemapped tiles are gathered to rank 0 over RCCL and assembled
+there, inside the timed region.  value = closest-hit queries of all ranks / time.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+VALU_PEAK_TFLOPS = 157.3     # fp32 vector peak (spec)
+
+WORKLOADS = {
+    # name: (scene builder, width, samples/dim, depth)   — SURVEY §8d
+    "C3-blob82k-1080p-16spp": (lambda S: S.blob_scene(6), 1920, 4, 5),
+    "C2-cornell-512-64spp": (lambda S: __import__("pathtracer_amd").Scene.from_text(S.cornell_ray()), 512, 8, 5),
+    "C5-glass-1024-16spp": (lambda S: __import__("pathtracer_amd").Scene.from_text(S.glass_ray()), 1024, 4, 8),
+    "C4-blob1.3M-4k-256spp": (lambda S: S.blob_scene(8), 3840, 16, 5),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="C3-blob82k-1080p-16spp", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch-paths", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import pathtracer_amd as P
+    from pathtracer_amd import scenes as S
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    build, width, samples, depth = WORKLOADS[args.workload]
+    scene = build(S)
+    w, h = scene.image_size(width)
+    ctx = P.Context(local_rank)
+    ctx.upload(scene)  # scene resident in HBM before any timed region
+
+    params = P.Context.params(w, h, samples, depth, seed=0, shard=(rank, world), batch_paths=args.batch_paths)
+    p0 = P.Context.params(w, h, samples, depth, seed=0, shard=(0, world))
+    stride = P.shard_pixels(p0)  # rank 0 owns the most tiles
+    rgba8 = torch.zeros(stride * 4, dtype=torch.uint8, device=dev)
+    gathered = torch.zeros(world * stride * 4, dtype=torch.uint8, device=dev) if (world > 1 and rank == 0) else None
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        st = ctx.render_device(params, None, rgba8.data_ptr(), stream)
+        img = None
+        if world > 1:
+            dist.gather(rgba8, list(gathered.view(world, -1).unbind(0)) if rank == 0 else None, dst=0)
+            if rank == 0:
+                torch.cuda.current_stream().synchronize()
+                img = ctx.assemble_rgb8(params, gathered.data_ptr(), stride)
+        return st, img
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    rays = 0
+    ms_extend = 0.0
+    n_ext = 0
+    for _ in range(args.steps):
+        st, img = step()
+        rays += st.rays_cast
+        ms_extend += st.ms_extend
+        n_ext += st.extend_launches
+    fence()
+    dt = time.perf_counter() - t0
+
+    tot = torch.tensor([float(rays), dt, ms_extend, float(n_ext)], dtype=torch.float64, device=dev)
+    if world > 1:
+        mx = tot.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = tot.clone()
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        dt_max, rays_all = mx[1].item(), sm[0].item()
+    else:
+        dt_max, rays_all = dt, float(rays)
+
+    if rank == 0:
+        # Roofline of the dominant kernel (k_extend) — algorithmic bytes of ITS OWN
+        # traversal, counted by the instrumented kernel variant outside the timed region.
+        pc = P.Context.params(w, h, samples, depth, seed=0, shard=(rank, world), batch_paths=args.batch_paths, count_work=True)
+        stc = ctx.render_device(pc, None, rgba8.data_ptr(), stream)
+        r = max(1, stc.rays_cast)
+        nodes_per_ray, leaves_per_ray = stc.node_visits / r, stc.prim_tests / r
+        bytes_per_ray = 64.0 * nodes_per_ray + 64.0 * leaves_per_ray + 128.0
+        flops_per_ray = 54.0 * nodes_per_ray + 37.0 * leaves_per_ray + 160.0
+        rays_rank0_per_step = rays / args.steps
+        launches_per_step = max(1, n_ext // args.steps)
+        avg_launch_ms = ms_extend / max(1, n_ext)
+        bytes_per_launch = bytes_per_ray * rays_rank0_per_step / launches_per_step
+        achieved_gbs = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
+        valu_tflops = flops_per_ray * rays_rank0_per_step / launches_per_step / (avg_launch_ms * 1e-3) / 1e12 if avg_launch_ms > 0 else 0.0
+        out = {
+            "metric": "Mrays/s (whole node), bunny-class scene 1080p",
+            "value": rays_all / dt_max / 1e6,
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt_max / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": args.workload, "image": [w, h], "samples_per_dim": samples, "depth": depth,
+                       "primitives": scene.n_prims, "bvh_depth": scene.bvh_depth, "sharding": f"tile32x{world}",
+                       "rays_per_step": rays_all / args.steps},
+            "roofline": {"bound": "hbm", "kernel": "k_extend", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "bytes_per_ray": bytes_per_ray, "nodes_per_ray": nodes_per_ray, "prim_tests_per_ray": leaves_per_ray,
+                         "avg_launch_ms": avg_launch_ms, "launches_per_step": launches_per_step,
+                         "valu_tflops": valu_tflops, "valu_frac": valu_tflops / VALU_PEAK_TFLOPS,
+                         "extend_share_of_step": (ms_extend / args.steps) / (dt / args.steps * 1e3)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(scene, w, h, samples, depth, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(scene, w, h, samples, depth, budget_s):
+    """The oracle (CPU restatement of CpuTracer, same flattened BVH, same RNG) timed on
+    this host's cores over a bounded band of rows of the same workload."""
+    import pathtracer_amd as P
+    from oracle import oracle_py as O
+    cores = min(16, len(os.sched_getaffinity(0)))
+    rows = 2
+    mid = h // 2
+    p = P.Context.params(w, h, samples, depth, seed=0)
+    # calibrate on 2 rows, then size the band for ~budget_s
+    _, _, c = O.render(scene, p, threads=cores, rows=(mid, mid + rows))
+    per_row = max(c.ms / rows, 1e-3)
+    rows = int(max(2, min(h, budget_s * 1e3 / per_row)))
+    y0 = max(0, mid - rows // 2)
+    _, _, c = O.render(scene, p, threads=cores, rows=(y0, min(h, y0 + rows)))
+    return {"value": c.rays / (c.ms * 1e-3) / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": f"rows [{y0},{min(h, y0 + rows)}) of the same {w}x{h} workload, {c.rays} rays in {c.ms / 1e3:.1f} s",
+            "nodes_per_ray": c.node_visits / max(1, c.rays), "prim_tests_per_ray": c.leaf_tests / max(1, c.rays)}
+
+
+if __name__ == "__main__":
+    main()

@@ -104,6 +104,10 @@ typedef struct mi_render_params {
     int32_t shard_rank;   /* this context renders tiles k with k % shard_count ==   */
     int32_t shard_count;  /*   shard_rank (row-major tile index); 0/1 -> everything */
     int64_t batch_paths;  /* max paths in flight per wavefront batch; 0 -> default  */
+    int32_t count_work;   /* != 0: run the instrumented extend kernel that counts node
+                             visits and primitive tests (slower; for roofline
+                             accounting, never inside a timed region)                */
+    int32_t reserved;
 } mi_render_params;
 
 typedef struct mi_stats {
@@ -115,6 +119,8 @@ typedef struct mi_stats {
     double ms_other;         /* generate + resolve                                  */
     uint32_t extend_launches;
     uint32_t batches;
+    uint64_t node_visits;    /* only with count_work: interior nodes fetched          */
+    uint64_t prim_tests;     /* only with count_work: primitive records tested        */
 } mi_stats;
 
 /* Create a context on HIP device `device_id`.  One context = one GPU; multi-GPU

@@ -47,6 +47,7 @@ class RenderParams(C.Structure):
         ("width", C.c_int32), ("height", C.c_int32), ("samples_per_dim", C.c_int32), ("depth", C.c_int32),
         ("seed", C.c_uint64), ("tile_w", C.c_int32), ("tile_h", C.c_int32),
         ("shard_rank", C.c_int32), ("shard_count", C.c_int32), ("batch_paths", C.c_int64),
+        ("count_work", C.c_int32), ("reserved", C.c_int32),
     ]
 
 
@@ -55,6 +56,7 @@ class Stats(C.Structure):
     _fields_ = [
         ("rays_cast", C.c_uint64), ("paths", C.c_uint64), ("ms_total", C.c_double), ("ms_extend", C.c_double),
         ("ms_shade", C.c_double), ("ms_other", C.c_double), ("extend_launches", C.c_uint32), ("batches", C.c_uint32),
+        ("node_visits", C.c_uint64), ("prim_tests", C.c_uint64),
     ]
 
 

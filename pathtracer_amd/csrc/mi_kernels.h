@@ -286,17 +286,20 @@ __device__ __forceinline__ bool slab(f3 bmin, f3 bmax, f3 o, f3 inv, float tmax,
 // Closest hit of one ray.  `stack` points at this lane's column of the LDS stack
 // (stride MI_BLOCK ints), `ovf` at its column of the global overflow (stride
 // ovf_stride).
-template <bool EXACT>
-__device__ __forceinline__ void traverse(const DevScene &sc, f3 o, f3 d, f3 inv, Hit &h, int *stack, int *ovf, size_t ovf_stride) {
+template <bool EXACT, bool COUNT>
+__device__ __forceinline__ void traverse(const DevScene &sc, f3 o, f3 d, f3 inv, Hit &h, int *stack, int *ovf, size_t ovf_stride,
+                                         uint32_t &n_nodes, uint32_t &n_leaves) {
     int cur = sc.root_ref;
     int sp = 0;
     for (;;) {
+        if (COUNT) n_nodes++;
         const float4 *nd = sc.nodes + 4 * (size_t)cur;
         float4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
         float tminL, tminR;
         bool hitL = slab<EXACT>(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), o, inv, h.t, tminL);
         bool hitR = slab<EXACT>(mk3(n1.z, n1.w, n2.x), mk3(n2.y, n2.z, n2.w), o, inv, h.t, tminR);
         int l = __float_as_int(n3.x), r = __float_as_int(n3.y);
+        if (COUNT) n_leaves += (hitL && l < 0) + (hitR && r < 0);
         if (hitL && l < 0) prim_test(sc, ~l, o, d, h);
         if (hitR && r < 0) prim_test(sc, ~r, o, d, h);
         // A child whose entry distance is already behind the best hit cannot
@@ -325,9 +328,13 @@ __device__ __forceinline__ void traverse(const DevScene &sc, f3 o, f3 d, f3 inv,
 // Persistent waves: each wave fetches 64 queue entries at a time from a shared
 // cursor until the queue is drained (every wave reaches the exit test).
 // queue == nullptr means the identity queue (slot = index).
+// COUNT = true is the instrumented build used once per bench run (outside the timed
+// region) to measure node visits and primitive tests per ray: work_stats[0] += node
+// visits, [1] += primitive tests.
+template <bool COUNT>
 __global__ void __launch_bounds__(MI_BLOCK)
 k_extend(DevScene sc, const uint32_t *queue, const uint32_t *count_ptr, uint32_t fixed_count, uint32_t *cursor,
-         const float4 *ray_o, const float4 *ray_d, float4 *hits, int *ovf) {
+         const float4 *ray_o, const float4 *ray_d, float4 *hits, int *ovf, unsigned long long *work_stats) {
     __shared__ int lds_stack[MI_LDS_STACK * MI_BLOCK];
     const uint32_t n = count_ptr ? *count_ptr : fixed_count;
     const int lane = threadIdx.x & 63;
@@ -335,6 +342,7 @@ k_extend(DevScene sc, const uint32_t *queue, const uint32_t *count_ptr, uint32_t
     const size_t ovf_stride = (size_t)gridDim.x * MI_BLOCK;
     int *my_ovf = ovf + (size_t)blockIdx.x * MI_BLOCK + threadIdx.x;
     const bool empty_scene = sc.n_tri + sc.n_sph == 0;
+    uint32_t n_nodes = 0, n_leaves = 0;
     for (;;) {
         uint32_t base = 0;
         if (lane == 0) base = atomicAdd(cursor, 64u);
@@ -349,14 +357,19 @@ k_extend(DevScene sc, const uint32_t *queue, const uint32_t *count_ptr, uint32_t
         Hit h{MI_NO_HIT, 0.0f, 0.0f, -1};
         if (!empty_scene) {                                  // bvh.cu:174-176,180-181
             if (sc.root_ref < 0) {                           // bvh.cu:182-183
+                if (COUNT) n_leaves++;
                 prim_test(sc, ~sc.root_ref, o, d, h);
             } else {
                 bool finite = __builtin_isfinite(inv.x) && __builtin_isfinite(inv.y) && __builtin_isfinite(inv.z);
-                if (finite) traverse<false>(sc, o, d, inv, h, stack, my_ovf, ovf_stride);
-                else traverse<true>(sc, o, d, inv, h, stack, my_ovf, ovf_stride);
+                if (finite) traverse<false, COUNT>(sc, o, d, inv, h, stack, my_ovf, ovf_stride, n_nodes, n_leaves);
+                else traverse<true, COUNT>(sc, o, d, inv, h, stack, my_ovf, ovf_stride, n_nodes, n_leaves);
             }
         }
         hits[slot] = make_float4(h.t, __int_as_float(h.slot), h.u, h.v);
+    }
+    if (COUNT) {
+        atomicAdd(&work_stats[0], (unsigned long long)n_nodes);
+        atomicAdd(&work_stats[1], (unsigned long long)n_leaves);
     }
 }
 

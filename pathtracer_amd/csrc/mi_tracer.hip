@@ -71,7 +71,7 @@ static const int kMaxLevels = 64; // counters reserved per batch (depth + 2 must
 
 static int extend_grid(const mi_ctx *c) { return c->n_cu * 4; } // 4 workgroups x 4 waves per CU
 
-MI_API int mi_abi_version(void) { return 1; }
+MI_API int mi_abi_version(void) { return 2; }
 MI_API const char *mi_last_error(void) { return g_err.c_str(); }
 
 MI_API mi_status mi_ctx_create(int device_id, mi_ctx **out) {
@@ -274,6 +274,7 @@ MI_API mi_status mi_render_device(mi_ctx *c, const mi_render_params *p, void *d_
     if (cap64 >= ((int64_t)1 << 32) - 64) return fail(MI_ERR_INVALID, "batch too large (samples_per_dim too high)");
     const size_t cap = (size_t)cap64;
     const int hist_levels = std::max(1, p->depth + 1);
+    const bool count_work = p->count_work != 0;
     HIPCHK(c->ray_o.ensure(cap * 16));
     HIPCHK(c->ray_d.ensure(cap * 16));
     HIPCHK(c->thr.ensure(cap * 16));
@@ -310,8 +311,12 @@ MI_API mi_status mi_render_device(mi_ctx *c, const mi_render_params *p, void *d_
         for (int k = 0; k < levels; k++) {
             uint32_t *qin = (k & 1) ? qb : qa, *qout = (k & 1) ? qa : qb;
             if (per_launch) HIPCHK(hipEventRecord(c->ev[evi++], st));
-            hipLaunchKernelGGL(k_extend, dim3(egrid), dim3(MI_BLOCK), 0, st, c->sc, qin, cnt + k, 0u, cur + k, c->ray_o.as<float4>(),
-                               c->ray_d.as<float4>(), c->hits.as<float4>(), c->ovf.as<int>());
+            if (count_work)
+                hipLaunchKernelGGL(k_extend<true>, dim3(egrid), dim3(MI_BLOCK), 0, st, c->sc, qin, cnt + k, 0u, cur + k, c->ray_o.as<float4>(),
+                                   c->ray_d.as<float4>(), c->hits.as<float4>(), c->ovf.as<int>(), c->totals.as<unsigned long long>() + 2);
+            else
+                hipLaunchKernelGGL(k_extend<false>, dim3(egrid), dim3(MI_BLOCK), 0, st, c->sc, qin, cnt + k, 0u, cur + k, c->ray_o.as<float4>(),
+                                   c->ray_d.as<float4>(), c->hits.as<float4>(), c->ovf.as<int>(), (unsigned long long *)nullptr);
             if (per_launch) HIPCHK(hipEventRecord(c->ev[evi++], st));
             hipLaunchKernelGGL(k_shade, dim3(sgrid), dim3(MI_BLOCK), 0, st, c->sc, g, pix0, np, k, p->depth - k, p->seed, qin, cnt + k,
                                c->ray_o.as<float4>(), c->ray_d.as<float4>(), c->thr.as<float4>(), c->hits.as<float4>(),
@@ -334,6 +339,8 @@ MI_API mi_status mi_render_device(mi_ctx *c, const mi_render_params *p, void *d_
         HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
         stats->ms_total = ms;
         stats->batches = (uint32_t)n_batches;
+        stats->node_visits = c->h_totals[2];
+        stats->prim_tests = c->h_totals[3];
         if (per_launch) {
             double me = 0, msh = 0;
             for (size_t i = 2; i + 3 <= evi; i += 3) {
@@ -409,8 +416,9 @@ static mi_status probe_chunk(mi_ctx *c, int64_t n, int32_t *prim_id_out, float *
     hipStream_t st = c->stream;
     uint32_t *cur = c->counters.as<uint32_t>();
     HIPCHK(hipMemsetAsync(cur, 0, 4, st));
-    hipLaunchKernelGGL(k_extend, dim3(extend_grid(c)), dim3(MI_BLOCK), 0, st, c->sc, (const uint32_t *)nullptr, (const uint32_t *)nullptr,
-                       (uint32_t)n, cur, c->ray_o.as<float4>(), c->ray_d.as<float4>(), c->hits.as<float4>(), c->ovf.as<int>());
+    hipLaunchKernelGGL(k_extend<false>, dim3(extend_grid(c)), dim3(MI_BLOCK), 0, st, c->sc, (const uint32_t *)nullptr, (const uint32_t *)nullptr,
+                       (uint32_t)n, cur, c->ray_o.as<float4>(), c->ray_d.as<float4>(), c->hits.as<float4>(), c->ovf.as<int>(),
+                       (unsigned long long *)nullptr);
     hipLaunchKernelGGL(k_probe_out, dim3((unsigned)((n + MI_BLOCK - 1) / MI_BLOCK)), dim3(MI_BLOCK), 0, st, c->sc, n, c->ray_o.as<float4>(),
                        c->ray_d.as<float4>(), c->hits.as<float4>(), c->probe_i.as<int32_t>(), c->probe_t.as<float>(),
                        n_out ? c->probe_n.as<float>() : nullptr);
