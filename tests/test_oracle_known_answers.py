@@ -1,0 +1,192 @@
+"""Known-answer tests that pin the CPU oracle.
+
+The reference ships no golden vectors for this path and cannot be built in this image
+(it needs CUDA headers and glm), so the oracle is "parity unpinned" against the
+reference itself.  What pins it here: analytic answers derived by hand from the cited
+formulas, the published Philox4x32-10 known-answer vectors, and an independent
+double-precision Python evaluation of the tonemap."""
+import math
+
+import numpy as np
+import pytest
+
+import pathtracer_amd as P
+from pathtracer_amd import scenes
+from oracle import oracle_py as O
+
+HDR = scenes.HEADER
+CAM = "camera { position = (0,0,5); viewdir = (0,0,-1); updir = (0,1,0); fov = 90; aspectratio = 1; }\n"
+
+
+def test_philox4x32_10_published_vectors():
+    # Random123 kat_vectors: philox4x32 10
+    assert [hex(x) for x in O.philox([0] * 4, [0] * 2)] == ["0x6627e8d5", "0xe169c58d", "0xbc57ac4c", "0x9b00dbd8"]
+    assert [hex(x) for x in O.philox([0xFFFFFFFF] * 4, [0xFFFFFFFF] * 2)] == ["0x408f276d", "0x41c83b0e", "0xa20bc7c6", "0x6d5451fd"]
+    assert [hex(x) for x in O.philox([0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344], [0xA4093822, 0x299F31D0])] == \
+        ["0xd16cfe09", "0x94fdcceb", "0x5001e420", "0x24126ea1"]
+
+
+def test_tonemap_matches_independent_double_evaluation():
+    def hable(x):  # tracer.cu:22-30
+        a, b, c, d, e, f = 0.15, 0.50, 0.10, 0.20, 0.02, 0.30
+        return ((x * (a * x + c * b) + d * e) / (x * (a * x + b) + d * f)) - e / f
+    for k in range(1025):
+        c = np.float32(k / 1024.0)
+        want = int(255.0 * (1.0 / hable(2.0)) * hable(2.0 * float(c)))
+        assert O.tonemap_byte(c) == want
+    assert O.tonemap_byte(0.0) == 0 and O.tonemap_byte(1.0) in (254, 255)
+
+
+def test_sphere_known_answers():
+    # unit sphere at the origin seen from (0,0,5) along -z: t = 4, N = +z (sphere.cu:5-35)
+    sc = P.Scene.from_text(HDR + CAM + "sphere { material = { diffuse = (1,1,1); } }\n")
+    rays = [[0, 0, 5, 0, 0, -1], [0, 0, 0, 0, 0, -1], [0, 3, 5, 0, 0, -1], [0, 0, 5, 0, 0, 1], [0.6, 0, 5, 0, 0, -1]]
+    ids, t, n, _ = O.trace_rays(sc, rays, O.BRUTE)
+    assert ids.tolist() == [0, 0, -1, -1, 0]
+    assert t[0] == 4.0 and np.allclose(n[0], [0, 0, 1])
+    assert t[1] == 1.0 and np.allclose(n[1], [0, 0, -1])      # from inside: far root, outward normal
+    assert t[2] == np.float32(12345678.9) and t[3] == np.float32(12345678.9)  # ISECT_NO_HIT, ray.h:14
+    assert abs(t[4] - (5 - 0.8)) < 1e-6 and np.allclose(n[4], [0.6, 0, 0.8], atol=1e-6)
+
+
+def test_sphere_uses_unnormalised_direction_for_normal_only():
+    # sphere.cu:7 normalises the direction for t, :26 evaluates r.at(t) with the raw one
+    sc = P.Scene.from_text(HDR + CAM + "sphere { material = { diffuse = (1,1,1); } }\n")
+    ids, t, n, _ = O.trace_rays(sc, [[0, 0, 5, 0, 0, -2]], O.BRUTE)
+    assert t[0] == 4.0                       # distance along the NORMALISED direction
+    assert np.allclose(n[0], [0, 0, -1])     # at(4) = 5 - 8 = -3 -> normalised (0,0,-1)
+
+
+def test_triangle_known_answers():
+    tri = "polymesh { material = { diffuse = (1,1,1); }; points = ((0,0,0),(1,0,0),(0,1,0)); faces = ((0,1,2)); }\n"
+    sc = P.Scene.from_text(HDR + CAM + tri)
+    rays = [[0.25, 0.25, 5, 0, 0, -1], [0.25, 0.25, -5, 0, 0, 1], [0.75, 0.75, 5, 0, 0, -1], [0.25, 0.25, 5, 0, 0, 1],
+            [0.5, 0.5, 5, 0, 0, -1], [0, 0, 5, 0, 0, -1]]
+    ids, t, n, _ = O.trace_rays(sc, rays, O.BRUTE)
+    assert ids.tolist() == [0, 0, -1, -1, 0, 0]          # u+v == 1 and a vertex are inside (trimesh.cu:104)
+    assert t[0] == 5.0 and t[1] == 5.0
+    assert np.allclose(n[0], [0, 0, 1]) and np.allclose(n[1], [0, 0, 1])  # geometric normal, never flipped
+
+
+def test_degenerate_faces_are_dropped():
+    tri = "polymesh { points = ((0,0,0),(1,0,0),(0,1,0),(0,0,0)); faces = ((0,1,2),(0,3,1),(1,1,2)); }\n"
+    sc = P.Scene.from_text(HDR + CAM + tri)
+    assert sc.n_prims == 1  # trimesh.cu:18-21
+
+
+def test_box_slab_semantics():
+    r = [0, 0, 5, 0, 0, -1]
+    assert O.box_intersect([-1, -1, -1], [1, 1, 1], r, 1e30)
+    assert not O.box_intersect([-1, -1, -1], [1, 1, 1], r, 3.9)      # tMax = best t cuts it off
+    assert O.box_intersect([-1, -1, -1], [1, 1, 1], r, 4.0)          # tMin <= tMax
+    assert not O.box_intersect([-1, -1, 6], [1, 1, 7], r, 1e30)      # behind the origin: tMax > 0 fails
+    assert not O.box_intersect([2, -1, -1], [3, 1, 1], r, 1e30)
+    # direction component 0 with the origin exactly on a slab plane -> 0*inf = NaN; the
+    # (a<b?a:b) macros of bbox.cu:4-5 then keep the second operand
+    assert O.box_intersect([0, -1, -1], [1, 1, 1], r, 1e30) == O.box_intersect([0, -1, -1], [1, 1, 1], r, 1e30)
+
+
+def test_triangle_precompute_is_the_inverse_basis():
+    rng = np.random.default_rng(0)
+    for _ in range(50):
+        v = np.zeros((3, 4), np.float32)
+        v[:, :3] = rng.uniform(-2, 2, (3, 3))
+        ok, (normal, uinv, vinv, ninv) = O.tri_precompute(v)
+        assert ok
+        ab, ac = (v[1] - v[0])[:3].astype(np.float64), (v[2] - v[0])[:3].astype(np.float64)
+        n = np.cross(ab, ac)
+        n /= np.linalg.norm(n)
+        assert np.allclose(normal[:3], n, atol=1e-5)
+        m = np.stack([uinv[:3], vinv[:3], ninv[:3]]).astype(np.float64)
+        assert np.allclose(m @ np.stack([ab, ac, n], 1), np.eye(3), atol=2e-4)
+
+
+def test_host_precompute_equals_oracle_precompute_bitwise(scenes_small):
+    for name in ("cornell", "blob3", "simple"):
+        sc = scenes_small[name]
+        s = sc.soa.contents
+        verts = sc.slot_vertices()
+        for arr_name, idx in (("tri_normal", 0), ("tri_uinv", 1), ("tri_vinv", 2), ("tri_ninv", 3)):
+            host = sc.array(arr_name, (s.n_tri, 4), np.float32)
+            for k in range(0, s.n_tri, max(1, s.n_tri // 97)):
+                ok, outs = O.tri_precompute(verts[k])
+                assert ok and np.array_equal(outs[idx].view(np.uint32), host[k].view(np.uint32)), (name, arr_name, k)
+
+
+def test_camera_setup_host_equals_oracle_and_analytic():
+    sc = P.Scene.from_text(HDR + "camera { position = (1,2,3); viewdir = (0,0,-1); updir = (0,1,0); fov = 90; aspectratio = 2; }\n")
+    s = sc.soa.contents
+    u, v, look = O.camera_from_look([0, 0, -1], [0, 1, 0], 90.0, 2.0)
+    assert list(s.cam_eye) == [1, 2, 3, 0]
+    assert np.array_equal(np.array(s.cam_u, np.float32), u) and np.array_equal(np.array(s.cam_v, np.float32), v)
+    assert np.array_equal(np.array(s.cam_look, np.float32), look)
+    nh = 2 * math.tan(math.radians(90) / 2)          # ~2 (camera.cu uses pi = 3.141592f)
+    assert np.allclose(u[:3], [nh * 2, 0, 0], atol=1e-5) and np.allclose(v[:3], [0, nh, 0], atol=1e-5)
+    assert np.allclose(look[:3], [0, 0, -1])
+
+
+def test_primary_rays_and_image_height_rule():
+    sc = P.Scene.from_text(scenes.simple_ray())
+    assert sc.image_size(256) == (256, 257) and sc.image_size(512) == (512, 513)
+    assert scenes.blob_scene(1).image_size(1920) == (1920, 1080)
+
+
+def test_sincos_polynomial_agrees_with_libm():
+    # deviation D3: the fmaf polynomial the HIP kernels share stays within 1.2e-7
+    # absolute (about 1 ulp at |x| ~ 1) of libm's sin/cos over [0, 2*pi]
+    for u in np.linspace(0, 1, 20001, dtype=np.float32):
+        p = np.float32(2 * np.float32(3.141592)) * u
+        s0, c0 = O.sincos(p, O.SINCOS_LIBM)
+        s1, c1 = O.sincos(p, O.SINCOS_POLY)
+        assert abs(s0 - s1) <= 1.2e-7 and abs(c0 - c1) <= 1.2e-7
+
+
+def test_hemisphere_sample_properties():
+    rng = np.random.default_rng(1)
+    for _ in range(200):
+        n = rng.normal(size=3)
+        n = (n / np.linalg.norm(n)).astype(np.float32)
+        u1, u2 = rng.random(2).astype(np.float32)
+        d = O.hemisphere(n, u1, u2, O.SINCOS_POLY)
+        assert abs(np.linalg.norm(d[:3]) - 1) < 1e-5 and d[3] == 0
+        assert abs(float(np.dot(d[:3], n)) - float(u2) ** 2) < 1e-5     # cos(theta) = u2^2, CpuTracer.cu:50
+    # basis switch at |N.x| <= 1e-5 (CpuTracer.cu:38-40)
+    d = O.hemisphere(np.array([0, 0, 1], np.float32), 0.0, 0.0, 1)
+    assert np.allclose(d[:3], [0, 1, 0], atol=1e-6) or np.allclose(d[:3], [0, -1, 0], atol=1e-6)
+
+
+def test_depth_means_up_to_d_plus_2_rays_and_white_background():
+    # empty scene: every path misses -> white (CpuTracer.cu:124-125), 1 ray per path
+    sc = P.Scene.from_text(HDR + CAM)
+    p = P.Context.params(8, 8, 1, 3)
+    mean, rgb, cnt = O.render(sc, p)
+    assert cnt.rays == 64 and np.all(mean == 1.0) and np.all(rgb == O.tonemap_byte(1.0))
+    # closed room of six INWARD-facing quads around the camera (a `box` would not do: its
+    # normals point outward and are never flipped, so bounces off its inside escape):
+    # no ray escapes and the throughput 0.9^k stays above the cut-off -> exactly D+2 rays
+    m = "material = { diffuse = (0.9,0.9,0.9); emissive = (0.01,0.01,0.01); }"
+    q = scenes._quad
+    room = HDR + "camera { position = (0,0,0); viewdir = (0,0,-1); updir = (0,1,0); fov = 60; aspectratio = 1; }\n"
+    room += q((-1, -1, 1), (1, -1, 1), (1, -1, -1), (-1, -1, -1), m) + q((-1, 1, 1), (-1, 1, -1), (1, 1, -1), (1, 1, 1), m)
+    room += q((-1, -1, -1), (1, -1, -1), (1, 1, -1), (-1, 1, -1), m) + q((-1, -1, 1), (-1, 1, 1), (1, 1, 1), (1, -1, 1), m)
+    room += q((-1, -1, 1), (-1, -1, -1), (-1, 1, -1), (-1, 1, 1), m) + q((1, -1, 1), (1, 1, 1), (1, 1, -1), (1, -1, -1), m)
+    sc = P.Scene.from_text(room)
+    for depth in (0, 1, 4):
+        _, _, cnt = O.render(sc, P.Context.params(8, 8, 1, depth))
+        assert cnt.rays == 64 * (depth + 2)
+
+
+def test_emission_is_scaled_by_32():
+    # camera inside an emissive sphere with kd = 0: value = ke*32 at the first hit, then the
+    # bounce has throughput 0 < threshold (CpuTracer.cu:121,131,185)
+    sc = P.Scene.from_text(HDR + CAM + "translate(0,0,5, scale(3, sphere { material = { emissive = (0.01,0.02,0.004); } }))\n")
+    mean, _, cnt = O.render(sc, P.Context.params(4, 4, 1, 2))
+    assert np.allclose(mean[..., :3], [0.32, 0.64, 0.128], rtol=1e-6) and cnt.rays == 16
+
+
+def test_raycheck_rms_subtracts_without_uint8_wraparound():
+    a = np.zeros((4, 4, 3), np.uint8)
+    b = np.full((4, 4, 3), 3, np.uint8)
+    assert O.raycheck_rms(a, b) == pytest.approx(3.0) and O.raycheck_rms(b, a) == pytest.approx(3.0)
+    b[0, 0, 0] = 255
+    assert O.raycheck_rms(a, b) == pytest.approx(math.sqrt((47 * 9 + 255 ** 2) / 48))
