@@ -156,10 +156,10 @@ static mi_status validate_scene(const mi_scene_soa *s) {
 
 MI_API mi_status mi_scene_upload(mi_ctx *c, const mi_scene_soa *s) {
     if (!c || !s) return fail(MI_ERR_INVALID, "mi_scene_upload: NULL argument");
+    c->has_scene = false; // a rejected or failed upload leaves the context without a scene
     mi_status vs = validate_scene(s);
     if (vs != MI_OK) return vs;
     HIPCHK(hipSetDevice(c->device));
-    c->has_scene = false;
     const size_t nt = s->n_tri, ns = s->n_sph;
     auto up = [&](DevBuf &b, const void *src, size_t bytes) -> hipError_t {
         hipError_t e = b.ensure(std::max<size_t>(bytes, 16));

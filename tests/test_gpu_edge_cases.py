@@ -213,15 +213,15 @@ def test_tracer_interface_matches_the_raw_abi(ctx, scenes_small):
     text = scenes.cornell_ray()
     t = P.HipTracer(depth=3, samples=2, seed=21)
     assert t.load_scene(text=text)
-    w = 72
-    h = int(round(w / t.aspect_ratio() + 0.5))
+    sc = P.Scene.from_text(text)
+    w, h = sc.image_size(72)          # CommandLineUI.cu:83-84 (std::round, half away from zero)
+    assert t.aspect_ratio() == sc.aspect
     t.trace_setup(w, h)
     t.trace_image(w, h)
     t.wait_render()
-    sc = P.Scene.from_text(text)
     ctx.upload(sc)
     rgb = ctx.render(P.Context.params(w, h, 2, 3, seed=21))[1]
-    assert (w, h) == sc.image_size(w) and np.array_equal(t.get_buffer(), rgb) and t.stats().rays_cast > w * h * 4
+    assert (w, h) == (72, 73) and np.array_equal(t.get_buffer(), rgb) and t.stats().rays_cast > w * h * 4
     assert not P.HipTracer().load_scene(text="SBT-raytracer 9.9\n")
 
 
