@@ -20,7 +20,7 @@
 #include <stdint.h>
 
 #define MI_BLOCK 256          // threads per workgroup = 4 waves of 64
-#define MI_LDS_STACK 32       // traversal stack entries per lane held in LDS
+#define MI_LDS_STACK 16       // traversal stack entries per lane held in LDS
 #define MI_MAX_STACK 64       // deepest tree the uploader accepts
 #define MI_NO_HIT 12345678.9f // ray.h:14
 #define MI_EPS 0.00001f       // ray.h:12
@@ -108,58 +108,71 @@ struct ShardGeom {
 };
 // Local pixel q (tile-major, row-major inside the tile; the order documented for
 // mi_render_device) -> image pixel.  Returns false for pixels of edge tiles that
-// fall outside the image.
-__device__ __forceinline__ bool local_to_pixel(const ShardGeom &g, int64_t q, int &px, int &py) {
-    int tpix = g.tile_w * g.tile_h;
-    int64_t j = q / tpix;
-    int off = (int)(q - j * tpix);
-    int64_t gt = g.rank + j * (int64_t)g.count;
-    int tx = (int)(gt % g.tiles_x), ty = (int)(gt / g.tiles_x);
-    px = tx * g.tile_w + off % g.tile_w;
-    py = ty * g.tile_h + off / g.tile_w;
-    return gt < g.n_tiles && px < g.width && py < g.height;
+// fall outside the image.  32-bit arithmetic: the host rejects images whose padded
+// pixel count does not fit (64-bit integer division is ~100 instructions on gfx950).
+__device__ __forceinline__ bool local_to_pixel(const ShardGeom &g, uint32_t q, int &px, int &py) {
+    uint32_t tpix = (uint32_t)(g.tile_w * g.tile_h);
+    uint32_t j = q / tpix;
+    uint32_t off = q - j * tpix;
+    uint32_t gt = (uint32_t)g.rank + j * (uint32_t)g.count;
+    uint32_t ty = gt / (uint32_t)g.tiles_x, tx = gt - ty * (uint32_t)g.tiles_x;
+    uint32_t oy = off / (uint32_t)g.tile_w, ox = off - oy * (uint32_t)g.tile_w;
+    px = (int)(tx * (uint32_t)g.tile_w + ox);
+    py = (int)(ty * (uint32_t)g.tile_h + oy);
+    return gt < (uint32_t)g.n_tiles && px < g.width && py < g.height;
 }
 // Path slots of a batch walk each tile in 8x8 sub-blocks so that one wave (64
 // consecutive slots) covers an 8x8 pixel patch: coherent primary rays.  `lp` is
-// the position inside the batch; returns the local pixel it renders.
-__device__ __forceinline__ int64_t slot_to_local(const ShardGeom &g, int64_t lp) {
+// the position inside the shard; returns the local pixel it renders.
+__device__ __forceinline__ uint32_t slot_to_local(const ShardGeom &g, uint32_t lp) {
     if ((g.tile_w & 7) || (g.tile_h & 7)) return lp;
-    int tpix = g.tile_w * g.tile_h;
-    int64_t j = lp / tpix;
-    int off = (int)(lp - j * tpix);
-    int sub = off >> 6, in = off & 63;
-    int sbx = sub % (g.tile_w >> 3), sby = sub / (g.tile_w >> 3);
-    int x = sbx * 8 + (in & 7), y = sby * 8 + (in >> 3);
-    return j * tpix + y * g.tile_w + x;
+    uint32_t tpix = (uint32_t)(g.tile_w * g.tile_h);
+    uint32_t j = lp / tpix;
+    uint32_t off = lp - j * tpix;
+    uint32_t sub = off >> 6, in = off & 63u;
+    uint32_t sbw = (uint32_t)g.tile_w >> 3;
+    uint32_t sby = sub / sbw, sbx = sub - sby * sbw;
+    uint32_t x = sbx * 8u + (in & 7u), y = sby * 8u + (in >> 3);
+    return j * tpix + y * (uint32_t)g.tile_w + x;
 }
 
-// Wave-level queue append: ballot + prefix popcount + one atomic per wave.
+// Queue append (ray-queue compaction): wave ballot + popcount prefix inside each wave,
+// the four wave totals combined through LDS, ONE global atomic per workgroup.  Must be
+// called by every thread of the workgroup (it contains barriers).
 __device__ __forceinline__ void queue_append(bool alive, uint32_t slot, uint32_t *queue, uint32_t *count) {
+    __shared__ uint32_t wave_cnt[MI_BLOCK / 64];
+    __shared__ uint32_t block_base;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned long long mask = __ballot(alive);
-    if (mask == 0) return;
-    int lane = threadIdx.x & 63;
-    int leader = __ffsll((long long)mask) - 1;
-    uint32_t base = 0;
-    if (lane == leader) base = atomicAdd(count, (uint32_t)__popcll(mask));
-    base = __shfl(base, leader, 64);
-    if (alive) queue[base + __popcll(mask & ((1ull << lane) - 1ull))] = slot;
+    if (lane == 0) wave_cnt[wave] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+        for (int w = 0; w < MI_BLOCK / 64; w++) total += wave_cnt[w];
+        block_base = total ? atomicAdd(count, total) : 0u;
+    }
+    __syncthreads();
+    uint32_t prefix = block_base;
+    for (int w = 0; w < wave; w++) prefix += wave_cnt[w];
+    if (alive) queue[prefix + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = slot;
+    __syncthreads(); // wave_cnt / block_base are reused by the next call
 }
 
 // ------------------------------------------------------------------ generate
 // One thread per slot of the batch; slot = sample * npix + lp.
 __global__ void __launch_bounds__(MI_BLOCK)
-k_generate(DevScene sc, ShardGeom g, int64_t pix0, int32_t npix, float4 *ray_o, float4 *ray_d, float4 *thr,
+k_generate(DevScene sc, ShardGeom g, uint32_t pix0, uint32_t npix, float4 *ray_o, float4 *ray_d, float4 *thr,
            float4 *path_out, uint32_t *queue, uint32_t *count) {
-    int64_t i = (int64_t)blockIdx.x * MI_BLOCK + threadIdx.x;
-    int spp = g.samples * g.samples;
+    uint32_t i = blockIdx.x * MI_BLOCK + threadIdx.x;
+    uint32_t spp = (uint32_t)(g.samples * g.samples);
     bool alive = false;
-    if (i < (int64_t)npix * spp) {
-        int samp = (int)(i / npix);
-        int lp = (int)(i - (int64_t)samp * npix);
+    if (i < npix * spp) {
+        uint32_t samp = i / npix;
+        uint32_t lp = i - samp * npix;
         int px, py;
         alive = local_to_pixel(g, slot_to_local(g, pix0 + lp), px, py);
         if (alive) {
-            int sx = samp / g.samples, sy = samp - sx * g.samples;
+            int sx = (int)(samp / (uint32_t)g.samples), sy = (int)samp - sx * g.samples;
             // CpuTracer.cu:103-105
             float xx = float(px) - 0.5f + (1 + 2 * sx) / (2.0f * g.samples);
             float yy = float(py) - 0.5f + (1 + 2 * sy) / (2.0f * g.samples);
@@ -174,7 +187,7 @@ k_generate(DevScene sc, ShardGeom g, int64_t pix0, int32_t npix, float4 *ray_o, 
             path_out[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         }
     }
-    queue_append(alive, (uint32_t)i, queue, count);
+    queue_append(alive, i, queue, count);
 }
 
 // Rays for mi_trace_primary: full image, index (j*W+i)*spp + sx*s+sy.
@@ -283,58 +296,34 @@ __device__ __forceinline__ bool slab(f3 bmin, f3 bmax, f3 o, f3 inv, float tmax,
     return tmin <= tmax && tmax > 0;
 }
 
-// Closest hit of one ray.  `stack` points at this lane's column of the LDS stack
-// (stride MI_BLOCK ints), `ovf` at its column of the global overflow (stride
-// ovf_stride).
-template <bool EXACT, bool COUNT>
-__device__ __forceinline__ void traverse(const DevScene &sc, f3 o, f3 d, f3 inv, Hit &h, int *stack, int *ovf, size_t ovf_stride,
-                                         uint32_t &n_nodes, uint32_t &n_leaves) {
-    int cur = sc.root_ref;
-    int sp = 0;
-    for (;;) {
-        if (COUNT) n_nodes++;
-        const float4 *nd = sc.nodes + 4 * (size_t)cur;
-        float4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
-        float tminL, tminR;
-        bool hitL = slab<EXACT>(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), o, inv, h.t, tminL);
-        bool hitR = slab<EXACT>(mk3(n1.z, n1.w, n2.x), mk3(n2.y, n2.z, n2.w), o, inv, h.t, tminR);
-        int l = __float_as_int(n3.x), r = __float_as_int(n3.y);
-        if (COUNT) n_leaves += (hitL && l < 0) + (hitR && r < 0);
-        if (hitL && l < 0) prim_test(sc, ~l, o, d, h);
-        if (hitR && r < 0) prim_test(sc, ~r, o, d, h);
-        // A child whose entry distance is already behind the best hit cannot
-        // contain a closer one (the reference re-tests the right box after the
-        // left subtree, bvh.cu:7-8, with the same outcome).
-        bool goL = hitL && l >= 0 && tminL <= h.t;
-        bool goR = hitR && r >= 0 && tminR <= h.t;
-        if (goL && goR) {
-            if (tminR < tminL) { int tmp = l; l = r; r = tmp; }
-            if (sp < MI_LDS_STACK) stack[sp * MI_BLOCK] = r;
-            else ovf[(size_t)(sp - MI_LDS_STACK) * ovf_stride] = r;
-            sp++;
-            cur = l;
-        } else if (goL) {
-            cur = l;
-        } else if (goR) {
-            cur = r;
-        } else {
-            if (sp == 0) break;
-            sp--;
-            cur = sp < MI_LDS_STACK ? stack[sp * MI_BLOCK] : ovf[(size_t)(sp - MI_LDS_STACK) * ovf_stride];
-        }
-    }
-}
-
-// Persistent waves: each wave fetches 64 queue entries at a time from a shared
-// cursor until the queue is drained (every wave reaches the exit test).
+// Persistent waves, per-lane ray refill, and leaf tests postponed to their own phase.
+//
+// Every lane runs a small state machine: `cur` = next interior node (MI_DONE when the
+// stack is empty), `pend0/pend1` = leaf primitives found but not yet tested.  In each
+// iteration the WAVE executes one of two code blocks:
+//   node phase — lanes without pending leaves fetch their node (64 B), slab-test both
+//                child boxes, queue leaf children as pending, descend near-first / pop;
+//   leaf phase — lanes with a pending leaf test one primitive (the only place the
+//                triangle/sphere code exists).
+// The leaf phase runs when at least `leaf_min` lanes wait for it (or nobody can do node
+// work), so the expensive primitive test executes with many lanes active instead of
+// once per node step for the few lanes that happen to have reached a leaf.  Postponing
+// a leaf test never changes the result: the closest hit is order independent (tie rule
+// above); only the culling distance h.t is momentarily stale.
+//
+// Work distribution and refill: see the comments in the kernel body.  Every wave leaves
+// through the same exit (work exhausted and no lane active).
 // queue == nullptr means the identity queue (slot = index).
 // COUNT = true is the instrumented build used once per bench run (outside the timed
 // region) to measure node visits and primitive tests per ray: work_stats[0] += node
 // visits, [1] += primitive tests.
+#define MI_DONE 0x7fffffff
+#define MI_NONE (-1)
 template <bool COUNT>
 __global__ void __launch_bounds__(MI_BLOCK)
 k_extend(DevScene sc, const uint32_t *queue, const uint32_t *count_ptr, uint32_t fixed_count, uint32_t *cursor,
-         const float4 *ray_o, const float4 *ray_d, float4 *hits, int *ovf, unsigned long long *work_stats) {
+         const float4 *ray_o, const float4 *ray_d, float4 *hits, int *ovf, unsigned long long *work_stats, int refill_min,
+         uint32_t static_eighths, int leaf_min) {
     __shared__ int lds_stack[MI_LDS_STACK * MI_BLOCK];
     const uint32_t n = count_ptr ? *count_ptr : fixed_count;
     const int lane = threadIdx.x & 63;
@@ -342,30 +331,147 @@ k_extend(DevScene sc, const uint32_t *queue, const uint32_t *count_ptr, uint32_t
     const size_t ovf_stride = (size_t)gridDim.x * MI_BLOCK;
     int *my_ovf = ovf + (size_t)blockIdx.x * MI_BLOCK + threadIdx.x;
     const bool empty_scene = sc.n_tri + sc.n_sph == 0;
+    const char *node_base = (const char *)sc.nodes;
+    // Work distribution in 64-ray chunks.  The first static_eighths/8 of the chunks are
+    // dealt statically, interleaved over the waves (wave w takes chunks w, w+W, w+2W, ...:
+    // no atomics, and every wave sees the same mix of image regions); the rest is pulled
+    // dynamically, 4 chunks per returning atomic (a single word sustains only ~90
+    // returning atomics/us), to even out the tail.
+    const uint32_t n_waves = gridDim.x * (MI_BLOCK / 64);
+    const uint32_t wave_id = blockIdx.x * (MI_BLOCK / 64) + (threadIdx.x >> 6);
+    const uint32_t n_chunks = (n + 63u) >> 6;
+    uint32_t static_per_wave = (uint32_t)(((uint64_t)n_chunks * static_eighths) / (8u * n_waves));
+    if (static_per_wave == 0) static_per_wave = 1;
+    const uint32_t dyn_first = static_per_wave * n_waves;           // first dynamically dealt chunk
+    uint32_t static_k = 0;                                          // wave-uniform
+    uint32_t rng_next = 0, rng_end = 0;                             // wave-uniform, in rays
+    bool exhausted = false;                                         // wave-uniform
     uint32_t n_nodes = 0, n_leaves = 0;
+
+    bool active = false, exact = false;
+    uint32_t slot = 0;
+    f3 o = mk3(0, 0, 0), d = mk3(0, 0, 0), inv = mk3(0, 0, 0);
+    Hit h{MI_NO_HIT, 0.0f, 0.0f, -1};
+    int cur = MI_DONE, sp = 0, pend0 = MI_NONE, pend1 = MI_NONE;
     for (;;) {
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(cursor, 64u);
-        base = __shfl(base, 0, 64);
-        if (base >= n) break;
-        uint32_t i = base + lane;
-        if (i >= n) continue;
-        uint32_t slot = queue ? queue[i] : i;
-        float4 o4 = ray_o[slot], d4 = ray_d[slot];
-        f3 o = xyz(o4), d = xyz(d4);
-        f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z); // ray.h:53-57,79-82
-        Hit h{MI_NO_HIT, 0.0f, 0.0f, -1};
-        if (!empty_scene) {                                  // bvh.cu:174-176,180-181
-            if (sc.root_ref < 0) {                           // bvh.cu:182-183
+        unsigned long long act = __ballot(active);
+        int n_idle = 64 - __popcll(act);
+        // Refill: whenever at least refill_min lanes are idle, hand them the next rays of
+        // this wave's current chunk range, so rays of different traversal length do not
+        // leave lanes idle for the rest of a 64-ray packet.
+        if (!exhausted && (n_idle >= refill_min || act == 0ull)) {
+            if (rng_next >= rng_end) {
+                uint32_t c0 = n_chunks, c1 = n_chunks; // next chunk range [c0, c1)
+                if (static_k < static_per_wave) {
+                    c0 = wave_id + static_k * n_waves;
+                    c1 = c0 + 1;
+                    static_k++;
+                } else if (dyn_first < n_chunks) {
+                    // a relaxed load first: waves that arrive after the queue is drained do
+                    // not add to the traffic on the cursor word
+                    uint32_t seen = 0;
+                    if (lane == 0) seen = __hip_atomic_load(cursor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    seen = __builtin_amdgcn_readfirstlane(seen);
+                    if (dyn_first + seen < n_chunks) {
+                        uint32_t got = 0;
+                        if (lane == 0) got = atomicAdd(cursor, 4u);
+                        got = __builtin_amdgcn_readfirstlane(got);
+                        c0 = dyn_first + got;
+                        c1 = c0 + 4;
+                    }
+                }
+                if (c0 >= n_chunks) {
+                    if (static_k >= static_per_wave) exhausted = true;
+                    rng_next = rng_end = 0;
+                } else {
+                    rng_next = c0 << 6;
+                    rng_end = (c1 << 6) < n ? (c1 << 6) : n;
+                }
+            }
+            if (rng_next < rng_end) {
+                uint32_t rank = (uint32_t)__popcll(~act & ((1ull << lane) - 1ull));
+                uint32_t idx = rng_next + rank;
+                uint32_t avail = rng_end - rng_next;
+                if (!active && rank < avail) {
+                    slot = queue ? queue[idx] : idx;
+                    float4 o4 = ray_o[slot], d4 = ray_d[slot];
+                    o = xyz(o4);
+                    d = xyz(d4);
+                    inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z); // ray.h:53-57,79-82
+                    exact = !(__builtin_isfinite(inv.x) && __builtin_isfinite(inv.y) && __builtin_isfinite(inv.z));
+                    h = Hit{MI_NO_HIT, 0.0f, 0.0f, -1};
+                    sp = 0;
+                    pend0 = pend1 = MI_NONE;
+                    active = true;
+                    if (empty_scene) {                       // bvh.cu:174-176,180-181
+                        cur = MI_DONE;
+                    } else if (sc.root_ref < 0) {            // bvh.cu:182-183
+                        pend0 = ~sc.root_ref;
+                        cur = MI_DONE;
+                    } else {
+                        cur = sc.root_ref;
+                    }
+                }
+                rng_next += (uint32_t)n_idle < avail ? (uint32_t)n_idle : avail;
+            }
+            act = __ballot(active);
+            if (act == 0ull) {
+                if (exhausted) break;
+                continue;
+            }
+        } else if (act == 0ull) {
+            break; // exhausted and nothing in flight
+        }
+
+        const bool want_leaf = active && pend0 != MI_NONE;
+        const bool want_node = active && pend0 == MI_NONE && cur != MI_DONE;
+        const int nl = __popcll(__ballot(want_leaf)), nn = __popcll(__ballot(want_node));
+        if (nl > 0 && (nl >= leaf_min || nn == 0)) {
+            if (want_leaf) { // leaf phase: one primitive per lane
                 if (COUNT) n_leaves++;
-                prim_test(sc, ~sc.root_ref, o, d, h);
+                prim_test(sc, pend0, o, d, h);
+                pend0 = pend1;
+                pend1 = MI_NONE;
+            }
+        } else if (want_node) { // node phase
+            if (COUNT) n_nodes++;
+            const char *nd = node_base + ((uint32_t)cur << 6);
+            float4 n0 = *(const float4 *)(nd), n1 = *(const float4 *)(nd + 16), n2 = *(const float4 *)(nd + 32);
+            int2 refs = *(const int2 *)(nd + 48);
+            float tminL, tminR;
+            bool hitL, hitR;
+            if (exact) {
+                hitL = slab<true>(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), o, inv, h.t, tminL);
+                hitR = slab<true>(mk3(n1.z, n1.w, n2.x), mk3(n2.y, n2.z, n2.w), o, inv, h.t, tminR);
             } else {
-                bool finite = __builtin_isfinite(inv.x) && __builtin_isfinite(inv.y) && __builtin_isfinite(inv.z);
-                if (finite) traverse<false, COUNT>(sc, o, d, inv, h, stack, my_ovf, ovf_stride, n_nodes, n_leaves);
-                else traverse<true, COUNT>(sc, o, d, inv, h, stack, my_ovf, ovf_stride, n_nodes, n_leaves);
+                hitL = slab<false>(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), o, inv, h.t, tminL);
+                hitR = slab<false>(mk3(n1.z, n1.w, n2.x), mk3(n2.y, n2.z, n2.w), o, inv, h.t, tminR);
+            }
+            int l = refs.x, r = refs.y;
+            if (hitL && l < 0) pend0 = ~l;
+            if (hitR && r < 0) { if (pend0 == MI_NONE) pend0 = ~r; else pend1 = ~r; }
+            bool goL = hitL && l >= 0, goR = hitR && r >= 0;
+            if (goL && goR) {
+                if (tminR < tminL) { int tmp = l; l = r; r = tmp; }
+                if (sp < MI_LDS_STACK) stack[sp * MI_BLOCK] = r;
+                else my_ovf[(size_t)(sp - MI_LDS_STACK) * ovf_stride] = r;
+                sp++;
+                cur = l;
+            } else if (goL) {
+                cur = l;
+            } else if (goR) {
+                cur = r;
+            } else if (sp == 0) {
+                cur = MI_DONE;
+            } else {
+                sp--;
+                cur = sp < MI_LDS_STACK ? stack[sp * MI_BLOCK] : my_ovf[(size_t)(sp - MI_LDS_STACK) * ovf_stride];
             }
         }
-        hits[slot] = make_float4(h.t, __int_as_float(h.slot), h.u, h.v);
+        if (active && cur == MI_DONE && pend0 == MI_NONE) {
+            hits[slot] = make_float4(h.t, __int_as_float(h.slot), h.u, h.v);
+            active = false;
+        }
     }
     if (COUNT) {
         atomicAdd(&work_stats[0], (unsigned long long)n_nodes);
@@ -436,13 +542,13 @@ __device__ __forceinline__ float4 clamp01_4(float4 a) { // vec.h:184-186, CpuTra
 
 // One thread per queue entry of level `level`; depth_left = D - level.
 __global__ void __launch_bounds__(MI_BLOCK)
-k_shade(DevScene sc, ShardGeom g, int64_t pix0, int32_t npix, int level, int depth_left, uint64_t seed,
+k_shade(DevScene sc, ShardGeom g, uint32_t pix0, uint32_t npix, int level, int depth_left, uint64_t seed,
         const uint32_t *queue, const uint32_t *count_ptr, float4 *ray_o, float4 *ray_d, float4 *thr, const float4 *hits,
         float4 *hist_e, float4 *hist_w, size_t cap, float4 *path_out, uint32_t *next_queue, uint32_t *next_count) {
     const uint32_t n = *count_ptr;
     const uint32_t stride = gridDim.x * MI_BLOCK;
-    // every lane of a wave runs the same number of iterations (queue_append uses wave-wide ops)
-    const uint32_t n_round = (n + 63u) & ~63u;
+    // every thread of a workgroup runs the same number of iterations (queue_append has barriers)
+    const uint32_t n_round = (n + (MI_BLOCK - 1u)) & ~(MI_BLOCK - 1u);
     for (uint32_t i = blockIdx.x * MI_BLOCK + threadIdx.x; i < n_round; i += stride) {
         bool alive = false;
         uint32_t slot = 0;
@@ -467,8 +573,8 @@ k_shade(DevScene sc, ShardGeom g, int64_t pix0, int32_t npix, int level, int dep
                     f3 hitOuter = o + (t - MI_EPS) * d; // :128
                     float reflect = m.kr.x, refract = m.kt.x; // :136-137
                     // path id = (j*W + i)*spp + sx*s + sy, the oracle's key
-                    int samp = (int)(slot / (uint32_t)npix);
-                    int lp = (int)(slot - (uint32_t)samp * (uint32_t)npix);
+                    uint32_t samp = slot / npix;
+                    uint32_t lp = slot - samp * npix;
                     int px, py;
                     local_to_pixel(g, slot_to_local(g, pix0 + lp), px, py);
                     uint64_t path = ((uint64_t)py * g.width + px) * (uint64_t)(g.samples * g.samples) + (uint64_t)samp;
@@ -534,11 +640,11 @@ __device__ __forceinline__ uint8_t tonemap_byte(float c) { // tracer.cu:97
 // One thread per local pixel of the batch, in OUTPUT order (row-major in tile):
 // mean over samples in the reference's order (sx outer, sy inner, CpuTracer.cu:101-108).
 __global__ void __launch_bounds__(MI_BLOCK)
-k_resolve(ShardGeom g, int64_t pix0, int32_t npix, const float4 *path_out, float4 *mean_out, uchar4 *rgba8_out) {
-    int lp = blockIdx.x * MI_BLOCK + threadIdx.x;
+k_resolve(ShardGeom g, uint32_t pix0, uint32_t npix, const float4 *path_out, float4 *mean_out, uchar4 *rgba8_out) {
+    uint32_t lp = blockIdx.x * MI_BLOCK + threadIdx.x;
     if (lp >= npix) return;
     int spp = g.samples * g.samples;
-    int64_t q = slot_to_local(g, pix0 + lp); // the local pixel this batch position rendered
+    uint32_t q = slot_to_local(g, pix0 + lp); // the local pixel this batch position rendered
     float4 sum = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     for (int s = 0; s < spp; s++) sum = add4(sum, path_out[(size_t)s * npix + lp]);
     float div = (float)g.samples * g.samples; // CpuTracer.cu:108
@@ -577,7 +683,7 @@ k_assemble(ShardGeom g, const uchar4 *gathered, int64_t shard_stride, int64_t sh
     int64_t i = (int64_t)blockIdx.x * MI_BLOCK + threadIdx.x;
     if (i >= shard_pixels * g.count) return;
     int r = (int)(i / shard_pixels);
-    int64_t q = i - (int64_t)r * shard_pixels;
+    uint32_t q = (uint32_t)(i - (int64_t)r * shard_pixels);
     ShardGeom gr = g;
     gr.rank = r;
     int px, py;

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -65,11 +66,16 @@ struct mi_ctx {
     DevBuf out_mean, out_rgba8, out_rgb8, probe_i, probe_t, probe_n;
     std::vector<hipEvent_t> ev;
     uint64_t *h_totals = nullptr; // pinned
+    // tuning knobs (defaults measured on MI355X, overridable through the environment)
+    int extend_wg_per_cu = 6;   // MI_TRACER_EXTEND_WG_PER_CU: persistent workgroups of k_extend per CU
+    int refill_min = 20;        // MI_TRACER_REFILL: idle lanes that trigger a refill
+    uint32_t static_eighths = 8; // MI_TRACER_STATIC_EIGHTHS: share of chunks dealt statically, in 1/8
+    int leaf_min = 16;          // MI_TRACER_LEAF_MIN: lanes with a pending leaf that trigger a leaf phase
 };
 
 static const int kMaxLevels = 64; // counters reserved per batch (depth + 2 must fit)
 
-static int extend_grid(const mi_ctx *c) { return c->n_cu * 4; } // 4 workgroups x 4 waves per CU
+static int extend_grid(const mi_ctx *c) { return c->n_cu * c->extend_wg_per_cu; }
 
 MI_API int mi_abi_version(void) { return 2; }
 MI_API const char *mi_last_error(void) { return g_err.c_str(); }
@@ -88,6 +94,16 @@ MI_API mi_status mi_ctx_create(int device_id, mi_ctx **out) {
     mi_ctx *c = new mi_ctx;
     c->device = device_id;
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    auto env_int = [](const char *name, int lo, int hi, int dflt) {
+        const char *v = getenv(name);
+        if (!v) return dflt;
+        int x = atoi(v);
+        return x < lo ? lo : (x > hi ? hi : x);
+    };
+    c->extend_wg_per_cu = env_int("MI_TRACER_EXTEND_WG_PER_CU", 1, 16, c->extend_wg_per_cu);
+    c->refill_min = env_int("MI_TRACER_REFILL", 1, 64, c->refill_min);
+    c->leaf_min = env_int("MI_TRACER_LEAF_MIN", 1, 64, c->leaf_min);
+    c->static_eighths = (uint32_t)env_int("MI_TRACER_STATIC_EIGHTHS", 0, 8, (int)c->static_eighths);
     hipError_t es = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (es != hipSuccess) { delete c; return fail(MI_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(es)); }
     es = hipHostMalloc((void **)&c->h_totals, 4 * sizeof(uint64_t), hipHostMallocDefault);
@@ -216,7 +232,7 @@ static mi_status make_geom(const mi_render_params *p, ShardGeom &g) {
     g.tiles_x = (g.width + g.tile_w - 1) / g.tile_w;
     int tiles_y = (g.height + g.tile_h - 1) / g.tile_h;
     int64_t nt = (int64_t)g.tiles_x * tiles_y;
-    if (nt > INT32_MAX) return fail(MI_ERR_INVALID, "too many tiles");
+    if (nt * g.tile_w * g.tile_h >= ((int64_t)1 << 31)) return fail(MI_ERR_INVALID, "image too large (padded pixel count must fit 31 bits)");
     g.n_tiles = (int32_t)nt;
     g.count = p->shard_count > 1 ? p->shard_count : 1;
     g.rank = p->shard_count > 1 ? p->shard_rank : 0;
@@ -266,7 +282,7 @@ MI_API mi_status mi_render_device(mi_ctx *c, const mi_render_params *p, void *d_
     const int64_t local = shard_pixels(g);
     const int spp = g.samples * g.samples;
     const int levels = p->depth + 2; // rays per path <= D+2 (CpuTracer.cu:119-131)
-    int64_t want = p->batch_paths > 0 ? p->batch_paths : (int64_t)8 << 20;
+    int64_t want = p->batch_paths > 0 ? p->batch_paths : (int64_t)64 << 20;
     want = std::min<int64_t>(want, (int64_t)1 << 30);
     int64_t npix_b = std::max<int64_t>(64, want / spp / 64 * 64);
     npix_b = std::min(npix_b, std::max<int64_t>(local, 1));
@@ -302,8 +318,8 @@ MI_API mi_status mi_render_device(mi_ctx *c, const mi_render_params *p, void *d_
     size_t evi = 2;
     const int sgrid = std::min<int64_t>((int64_t)c->n_cu * 8, (cap + MI_BLOCK - 1) / MI_BLOCK);
     for (int64_t b = 0; b < n_batches; b++) {
-        const int64_t pix0 = b * npix_b;
-        const int32_t np = (int32_t)std::min<int64_t>(npix_b, local - pix0);
+        const uint32_t pix0 = (uint32_t)(b * npix_b);
+        const uint32_t np = (uint32_t)std::min<int64_t>(npix_b, local - (int64_t)pix0);
         const int64_t nslots = (int64_t)np * spp;
         HIPCHK(hipMemsetAsync(cnt, 0, 2 * (kMaxLevels + 1) * 4, st));
         hipLaunchKernelGGL(k_generate, dim3((unsigned)((nslots + MI_BLOCK - 1) / MI_BLOCK)), dim3(MI_BLOCK), 0, st, c->sc, g, pix0, np,
@@ -313,10 +329,10 @@ MI_API mi_status mi_render_device(mi_ctx *c, const mi_render_params *p, void *d_
             if (per_launch) HIPCHK(hipEventRecord(c->ev[evi++], st));
             if (count_work)
                 hipLaunchKernelGGL(k_extend<true>, dim3(egrid), dim3(MI_BLOCK), 0, st, c->sc, qin, cnt + k, 0u, cur + k, c->ray_o.as<float4>(),
-                                   c->ray_d.as<float4>(), c->hits.as<float4>(), c->ovf.as<int>(), c->totals.as<unsigned long long>() + 2);
+                                   c->ray_d.as<float4>(), c->hits.as<float4>(), c->ovf.as<int>(), c->totals.as<unsigned long long>() + 2, c->refill_min, c->static_eighths, c->leaf_min);
             else
                 hipLaunchKernelGGL(k_extend<false>, dim3(egrid), dim3(MI_BLOCK), 0, st, c->sc, qin, cnt + k, 0u, cur + k, c->ray_o.as<float4>(),
-                                   c->ray_d.as<float4>(), c->hits.as<float4>(), c->ovf.as<int>(), (unsigned long long *)nullptr);
+                                   c->ray_d.as<float4>(), c->hits.as<float4>(), c->ovf.as<int>(), (unsigned long long *)nullptr, c->refill_min, c->static_eighths, c->leaf_min);
             if (per_launch) HIPCHK(hipEventRecord(c->ev[evi++], st));
             hipLaunchKernelGGL(k_shade, dim3(sgrid), dim3(MI_BLOCK), 0, st, c->sc, g, pix0, np, k, p->depth - k, p->seed, qin, cnt + k,
                                c->ray_o.as<float4>(), c->ray_d.as<float4>(), c->thr.as<float4>(), c->hits.as<float4>(),
@@ -418,7 +434,7 @@ static mi_status probe_chunk(mi_ctx *c, int64_t n, int32_t *prim_id_out, float *
     HIPCHK(hipMemsetAsync(cur, 0, 4, st));
     hipLaunchKernelGGL(k_extend<false>, dim3(extend_grid(c)), dim3(MI_BLOCK), 0, st, c->sc, (const uint32_t *)nullptr, (const uint32_t *)nullptr,
                        (uint32_t)n, cur, c->ray_o.as<float4>(), c->ray_d.as<float4>(), c->hits.as<float4>(), c->ovf.as<int>(),
-                       (unsigned long long *)nullptr);
+                       (unsigned long long *)nullptr, c->refill_min, c->static_eighths, c->leaf_min);
     hipLaunchKernelGGL(k_probe_out, dim3((unsigned)((n + MI_BLOCK - 1) / MI_BLOCK)), dim3(MI_BLOCK), 0, st, c->sc, n, c->ray_o.as<float4>(),
                        c->ray_d.as<float4>(), c->hits.as<float4>(), c->probe_i.as<int32_t>(), c->probe_t.as<float>(),
                        n_out ? c->probe_n.as<float>() : nullptr);
