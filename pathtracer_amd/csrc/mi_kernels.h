@@ -159,35 +159,25 @@ __device__ __forceinline__ void queue_append(bool alive, uint32_t slot, uint32_t
 }
 
 // ------------------------------------------------------------------ generate
-// One thread per slot of the batch; slot = sample * npix + lp.
-__global__ void __launch_bounds__(MI_BLOCK)
-k_generate(DevScene sc, ShardGeom g, uint32_t pix0, uint32_t npix, float4 *ray_o, float4 *ray_d, float4 *thr,
-           float4 *path_out, uint32_t *queue, uint32_t *count) {
-    uint32_t i = blockIdx.x * MI_BLOCK + threadIdx.x;
-    uint32_t spp = (uint32_t)(g.samples * g.samples);
-    bool alive = false;
-    if (i < npix * spp) {
-        uint32_t samp = i / npix;
-        uint32_t lp = i - samp * npix;
-        int px, py;
-        alive = local_to_pixel(g, slot_to_local(g, pix0 + lp), px, py);
-        if (alive) {
-            int sx = (int)(samp / (uint32_t)g.samples), sy = (int)samp - sx * g.samples;
-            // CpuTracer.cu:103-105
-            float xx = float(px) - 0.5f + (1 + 2 * sx) / (2.0f * g.samples);
-            float yy = float(py) - 0.5f + (1 + 2 * sy) / (2.0f * g.samples);
-            float x = xx / float(g.width), y = yy / float(g.height);
-            x -= 0.5f; // camera.cu:11-12
-            y -= 0.5f;
-            f3 dir = normalize3(xyz(sc.look) + x * xyz(sc.u) + y * xyz(sc.v)); // camera.cu:13
-            ray_o[i] = make_float4(sc.eye.x, sc.eye.y, sc.eye.z, 0.0f);
-            ray_d[i] = make_float4(dir.x, dir.y, dir.z, 0.0f);
-            thr[i] = make_float4(1.0f, 1.0f, 1.0f, 1.0f); // traceRay(r, 1, depth), CpuTracer.cu:114
-        } else {
-            path_out[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        }
-    }
-    queue_append(alive, i, queue, count);
+// Camera ray of batch slot `slot` (= sample * npix + position in batch).  There is no
+// generate kernel and no stored primary ray: level 0 of k_extend and of k_shade both
+// call this (camera.cu:6-16 is ~30 instructions; a stored ray is 32 B written + 64 B
+// read).  Returns false for slots of edge tiles that fall outside the image.
+__device__ __forceinline__ bool primary_ray(const DevScene &sc, const ShardGeom &g, uint32_t pix0, uint32_t npix, uint32_t slot,
+                                            f3 &o, f3 &dir, int &px, int &py, uint32_t &samp) {
+    samp = slot / npix;
+    uint32_t lp = slot - samp * npix;
+    if (!local_to_pixel(g, slot_to_local(g, pix0 + lp), px, py)) return false;
+    int sx = (int)(samp / (uint32_t)g.samples), sy = (int)samp - sx * g.samples;
+    // CpuTracer.cu:103-105
+    float xx = float(px) - 0.5f + (1 + 2 * sx) / (2.0f * g.samples);
+    float yy = float(py) - 0.5f + (1 + 2 * sy) / (2.0f * g.samples);
+    float x = xx / float(g.width), y = yy / float(g.height);
+    x -= 0.5f; // camera.cu:11-12
+    y -= 0.5f;
+    dir = normalize3(xyz(sc.look) + x * xyz(sc.u) + y * xyz(sc.v)); // camera.cu:13
+    o = xyz(sc.eye);
+    return true;
 }
 
 // Rays for mi_trace_primary: full image, index (j*W+i)*spp + sx*s+sy.
@@ -228,22 +218,23 @@ __device__ __forceinline__ bool tie_allows(const DevScene &sc, int best_slot, in
     return best_is_sphere ? (cid < bid) : false;
 }
 
-__device__ __forceinline__ void tri_test(const DevScene &sc, int slot, f3 o, f3 d, Hit &h) { // trimesh.cu:87-121
-    const float4 *rec = sc.tri + 4 * (size_t)slot;
-    float4 v0 = rec[0], ni = rec[3];
+// trimesh.cu:87-121.  Evaluated without early exits: all four 16-B loads of the 64-B
+// record are issued together (one memory round trip instead of two) and the reject
+// tests of :92, :96 and :104 — each a pure function of the same values — are combined
+// at the end.  The accepted (t, u, v) are the reference's.
+__device__ __forceinline__ void tri_test(const DevScene &sc, int slot, f3 o, f3 d, Hit &h) {
+    const char *rec = (const char *)sc.tri + ((uint32_t)slot << 6);
+    float4 v0 = *(const float4 *)(rec), ui = *(const float4 *)(rec + 16), vi = *(const float4 *)(rec + 32), ni = *(const float4 *)(rec + 48);
     f3 p = o - xyz(v0);
     float pz = dot3(xyz(ni), p);
     float dz = dot3(xyz(ni), d);
-    if ((pz < 0) == (dz < 0)) return;
     float t = -pz / dz;
-    if (t > h.t) return;
-    if (t == h.t && !tie_allows(sc, h.slot, slot, true)) return;
-    float4 ui = rec[1], vi = rec[2];
     f3 hit = p + t * d;
     float u = dot3(xyz(ui), hit);
     float v = dot3(xyz(vi), hit);
-    if (u < 0 || u > 1 || v < 0 || v > 1 || u + v > 1) return;
-    h.t = t; h.u = u; h.v = v; h.slot = slot;
+    bool ok = ((pz < 0) != (dz < 0)) && !(t > h.t) && !(u < 0 || u > 1 || v < 0 || v > 1 || u + v > 1);
+    if (ok && t == h.t) ok = tie_allows(sc, h.slot, slot, true);
+    if (ok) { h.t = t; h.u = u; h.v = v; h.slot = slot; }
 }
 
 __device__ __forceinline__ void sphere_test(const DevScene &sc, int slot, f3 o, f3 d, Hit &h) { // sphere.cu:5-35
@@ -319,11 +310,14 @@ __device__ __forceinline__ bool slab(f3 bmin, f3 bmax, f3 o, f3 inv, float tmax,
 // visits, [1] += primitive tests.
 #define MI_DONE 0x7fffffff
 #define MI_NONE (-1)
-template <bool COUNT>
+// PRIMARY = true is level 0: the queue is the identity over the batch's slots, rays
+// come from primary_ray(), and the number of slots that are real pixels is added to
+// *primary_count (it is the level-0 ray count).
+template <bool COUNT, bool PRIMARY>
 __global__ void __launch_bounds__(MI_BLOCK)
 k_extend(DevScene sc, const uint32_t *queue, const uint32_t *count_ptr, uint32_t fixed_count, uint32_t *cursor,
          const float4 *ray_o, const float4 *ray_d, float4 *hits, int *ovf, unsigned long long *work_stats, int refill_min,
-         uint32_t static_eighths, int leaf_min) {
+         uint32_t static_eighths, int leaf_min, ShardGeom g, uint32_t pix0, uint32_t npix, uint32_t *primary_count) {
     __shared__ int lds_stack[MI_LDS_STACK * MI_BLOCK];
     const uint32_t n = count_ptr ? *count_ptr : fixed_count;
     const int lane = threadIdx.x & 63;
@@ -346,7 +340,8 @@ k_extend(DevScene sc, const uint32_t *queue, const uint32_t *count_ptr, uint32_t
     uint32_t static_k = 0;                                          // wave-uniform
     uint32_t rng_next = 0, rng_end = 0;                             // wave-uniform, in rays
     bool exhausted = false;                                         // wave-uniform
-    uint32_t n_nodes = 0, n_leaves = 0;
+    uint32_t n_nodes = 0, n_leaves = 0, ray_steps = 0, max_ray_steps = 0, wave_iters = 0;
+    uint32_t n_primary = 0; // wave-uniform
 
     bool active = false, exact = false;
     uint32_t slot = 0;
@@ -392,11 +387,22 @@ k_extend(DevScene sc, const uint32_t *queue, const uint32_t *count_ptr, uint32_t
                 uint32_t rank = (uint32_t)__popcll(~act & ((1ull << lane) - 1ull));
                 uint32_t idx = rng_next + rank;
                 uint32_t avail = rng_end - rng_next;
-                if (!active && rank < avail) {
+                bool take = !active && rank < avail;
+                if (PRIMARY) {
+                    if (take) {
+                        slot = idx;
+                        int px, py;
+                        uint32_t samp;
+                        take = primary_ray(sc, g, pix0, npix, slot, o, d, px, py, samp);
+                    }
+                    n_primary += (uint32_t)__popcll(__ballot(take));
+                } else if (take) {
                     slot = queue ? queue[idx] : idx;
                     float4 o4 = ray_o[slot], d4 = ray_d[slot];
                     o = xyz(o4);
                     d = xyz(d4);
+                }
+                if (take) {
                     inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z); // ray.h:53-57,79-82
                     exact = !(__builtin_isfinite(inv.x) && __builtin_isfinite(inv.y) && __builtin_isfinite(inv.z));
                     h = Hit{MI_NO_HIT, 0.0f, 0.0f, -1};
@@ -423,6 +429,7 @@ k_extend(DevScene sc, const uint32_t *queue, const uint32_t *count_ptr, uint32_t
             break; // exhausted and nothing in flight
         }
 
+        if (COUNT) wave_iters++;
         const bool want_leaf = active && pend0 != MI_NONE;
         const bool want_node = active && pend0 == MI_NONE && cur != MI_DONE;
         const int nl = __popcll(__ballot(want_leaf)), nn = __popcll(__ballot(want_node));
@@ -434,7 +441,7 @@ k_extend(DevScene sc, const uint32_t *queue, const uint32_t *count_ptr, uint32_t
                 pend1 = MI_NONE;
             }
         } else if (want_node) { // node phase
-            if (COUNT) n_nodes++;
+            if (COUNT) { n_nodes++; ray_steps++; }
             const char *nd = node_base + ((uint32_t)cur << 6);
             float4 n0 = *(const float4 *)(nd), n1 = *(const float4 *)(nd + 16), n2 = *(const float4 *)(nd + 32);
             int2 refs = *(const int2 *)(nd + 48);
@@ -471,9 +478,13 @@ k_extend(DevScene sc, const uint32_t *queue, const uint32_t *count_ptr, uint32_t
         if (active && cur == MI_DONE && pend0 == MI_NONE) {
             hits[slot] = make_float4(h.t, __int_as_float(h.slot), h.u, h.v);
             active = false;
+            if (COUNT) { max_ray_steps = max(max_ray_steps, ray_steps); ray_steps = 0; }
         }
     }
+    if (PRIMARY && lane == 0 && n_primary) atomicAdd(primary_count, n_primary);
     if (COUNT) {
+        atomicMax(&work_stats[2], (unsigned long long)max_ray_steps);
+        if (lane == 0) { atomicAdd(&work_stats[3], (unsigned long long)wave_iters); atomicMax(&work_stats[4], (unsigned long long)wave_iters); }
         atomicAdd(&work_stats[0], (unsigned long long)n_nodes);
         atomicAdd(&work_stats[1], (unsigned long long)n_leaves);
     }
@@ -540,28 +551,45 @@ __device__ __forceinline__ float4 clamp01_4(float4 a) { // vec.h:184-186, CpuTra
                        fminf(fmaxf(a.w, 0.0f), 1.0f));
 }
 
-// One thread per queue entry of level `level`; depth_left = D - level.
+// One thread per queue entry of level `level`; depth_left = D - level.  PRIMARY = true
+// is level 0: identity queue over the batch's n_fixed slots, ray from primary_ray(),
+// throughput (1,1,1,1) (traceRay(r, 1, depth), CpuTracer.cu:114); slots that are not
+// pixels get a zero path value.
+template <bool PRIMARY>
 __global__ void __launch_bounds__(MI_BLOCK)
 k_shade(DevScene sc, ShardGeom g, uint32_t pix0, uint32_t npix, int level, int depth_left, uint64_t seed,
         const uint32_t *queue, const uint32_t *count_ptr, float4 *ray_o, float4 *ray_d, float4 *thr, const float4 *hits,
-        float4 *hist_e, float4 *hist_w, size_t cap, float4 *path_out, uint32_t *next_queue, uint32_t *next_count) {
-    const uint32_t n = *count_ptr;
+        float4 *hist_e, float4 *hist_w, size_t cap, float4 *path_out, uint32_t *next_queue, uint32_t *next_count, uint32_t n_fixed) {
+    const uint32_t n = PRIMARY ? n_fixed : *count_ptr;
     const uint32_t stride = gridDim.x * MI_BLOCK;
     // every thread of a workgroup runs the same number of iterations (queue_append has barriers)
     const uint32_t n_round = (n + (MI_BLOCK - 1u)) & ~(MI_BLOCK - 1u);
     for (uint32_t i = blockIdx.x * MI_BLOCK + threadIdx.x; i < n_round; i += stride) {
         bool alive = false;
         uint32_t slot = 0;
-        if (i < n) {
-            slot = queue[i];
+        bool live = i < n;
+        f3 o = mk3(0, 0, 0), d = mk3(0, 0, 0);
+        int px = 0, py = 0;
+        uint32_t samp = 0;
+        if (live) {
+            slot = PRIMARY ? i : queue[i];
+            if (PRIMARY) {
+                live = primary_ray(sc, g, pix0, npix, slot, o, d, px, py, samp);
+                if (!live) path_out[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
+        }
+        if (live) {
             float4 h4 = hits[slot];
             float t = h4.x;
             int pslot = __float_as_int(h4.y);
-            float4 T = thr[slot];
+            float4 T = PRIMARY ? make_float4(1.0f, 1.0f, 1.0f, 1.0f) : thr[slot];
             if (pslot < 0) { // CpuTracer.cu:124-125: miss -> (1,1,1,1)
                 path_out[slot] = clamp01_4(fold_history(hist_e, hist_w, cap, slot, level, make_float4(1.0f, 1.0f, 1.0f, 1.0f)));
             } else {
-                f3 o = xyz(ray_o[slot]), d = xyz(ray_d[slot]);
+                if (!PRIMARY) {
+                    o = xyz(ray_o[slot]);
+                    d = xyz(ray_d[slot]);
+                }
                 f3 N;
                 DMat m;
                 hit_surface(sc, pslot, t, h4.z, h4.w, o, d, N, m);
@@ -573,10 +601,11 @@ k_shade(DevScene sc, ShardGeom g, uint32_t pix0, uint32_t npix, int level, int d
                     f3 hitOuter = o + (t - MI_EPS) * d; // :128
                     float reflect = m.kr.x, refract = m.kt.x; // :136-137
                     // path id = (j*W + i)*spp + sx*s + sy, the oracle's key
-                    uint32_t samp = slot / npix;
-                    uint32_t lp = slot - samp * npix;
-                    int px, py;
-                    local_to_pixel(g, slot_to_local(g, pix0 + lp), px, py);
+                    if (!PRIMARY) {
+                        samp = slot / npix;
+                        uint32_t lp = slot - samp * npix;
+                        local_to_pixel(g, slot_to_local(g, pix0 + lp), px, py);
+                    }
                     uint64_t path = ((uint64_t)py * g.width + px) * (uint64_t)(g.samples * g.samples) + (uint64_t)samp;
                     uint32_t ctr[4] = {(uint32_t)path, (uint32_t)(path >> 32), (uint32_t)level, 0u};
                     philox4x32_10(ctr, (uint32_t)seed, (uint32_t)(seed >> 32));

@@ -106,7 +106,7 @@ MI_API mi_status mi_ctx_create(int device_id, mi_ctx **out) {
     c->static_eighths = (uint32_t)env_int("MI_TRACER_STATIC_EIGHTHS", 0, 8, (int)c->static_eighths);
     hipError_t es = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (es != hipSuccess) { delete c; return fail(MI_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(es)); }
-    es = hipHostMalloc((void **)&c->h_totals, 4 * sizeof(uint64_t), hipHostMallocDefault);
+    es = hipHostMalloc((void **)&c->h_totals, 8 * sizeof(uint64_t), hipHostMallocDefault);
     if (es != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return fail(MI_ERR_HIP, "hipHostMalloc failed: %s", hipGetErrorString(es)); }
     *out = c;
     return MI_OK;
@@ -303,7 +303,7 @@ MI_API mi_status mi_render_device(mi_ctx *c, const mi_render_params *p, void *d_
     HIPCHK(c->counters.ensure(2 * (kMaxLevels + 1) * 4));
     const int egrid = extend_grid(c);
     HIPCHK(c->ovf.ensure((size_t)(MI_MAX_STACK - MI_LDS_STACK) * egrid * MI_BLOCK * 4));
-    HIPCHK(c->totals.ensure(4 * 8));
+    HIPCHK(c->totals.ensure(8 * 8));
     const int64_t n_batches = local > 0 ? (local + npix_b - 1) / npix_b : 0;
     const size_t n_ev = 2 + (size_t)n_batches * levels * 3;
     const bool per_launch = n_ev <= 4096; // per-launch timing only while the event count stays modest
@@ -313,7 +313,7 @@ MI_API mi_status mi_render_device(mi_ctx *c, const mi_render_params *p, void *d_
     uint32_t *cnt = c->counters.as<uint32_t>();          // cnt[k] = queue length at level k
     uint32_t *cur = cnt + (kMaxLevels + 1);              // cur[k] = work cursor of extend at level k
     uint32_t *qa = c->queue_a.as<uint32_t>(), *qb = c->queue_b.as<uint32_t>();
-    HIPCHK(hipMemsetAsync(c->totals.p, 0, 32, st));
+    HIPCHK(hipMemsetAsync(c->totals.p, 0, 64, st));
     HIPCHK(hipEventRecord(c->ev[0], st));
     size_t evi = 2;
     const int sgrid = std::min<int64_t>((int64_t)c->n_cu * 8, (cap + MI_BLOCK - 1) / MI_BLOCK);
@@ -322,21 +322,30 @@ MI_API mi_status mi_render_device(mi_ctx *c, const mi_render_params *p, void *d_
         const uint32_t np = (uint32_t)std::min<int64_t>(npix_b, local - (int64_t)pix0);
         const int64_t nslots = (int64_t)np * spp;
         HIPCHK(hipMemsetAsync(cnt, 0, 2 * (kMaxLevels + 1) * 4, st));
-        hipLaunchKernelGGL(k_generate, dim3((unsigned)((nslots + MI_BLOCK - 1) / MI_BLOCK)), dim3(MI_BLOCK), 0, st, c->sc, g, pix0, np,
-                           c->ray_o.as<float4>(), c->ray_d.as<float4>(), c->thr.as<float4>(), c->path_out.as<float4>(), qa, cnt);
         for (int k = 0; k < levels; k++) {
             uint32_t *qin = (k & 1) ? qb : qa, *qout = (k & 1) ? qa : qb;
+            unsigned long long *ws = count_work ? c->totals.as<unsigned long long>() + 2 : nullptr;
             if (per_launch) HIPCHK(hipEventRecord(c->ev[evi++], st));
-            if (count_work)
-                hipLaunchKernelGGL(k_extend<true>, dim3(egrid), dim3(MI_BLOCK), 0, st, c->sc, qin, cnt + k, 0u, cur + k, c->ray_o.as<float4>(),
-                                   c->ray_d.as<float4>(), c->hits.as<float4>(), c->ovf.as<int>(), c->totals.as<unsigned long long>() + 2, c->refill_min, c->static_eighths, c->leaf_min);
-            else
-                hipLaunchKernelGGL(k_extend<false>, dim3(egrid), dim3(MI_BLOCK), 0, st, c->sc, qin, cnt + k, 0u, cur + k, c->ray_o.as<float4>(),
-                                   c->ray_d.as<float4>(), c->hits.as<float4>(), c->ovf.as<int>(), (unsigned long long *)nullptr, c->refill_min, c->static_eighths, c->leaf_min);
+#define MI_EXTEND_ARGS(PRIM)                                                                                                   \
+    dim3(egrid), dim3(MI_BLOCK), 0, st, c->sc, (PRIM) ? (const uint32_t *)nullptr : qin, (PRIM) ? (const uint32_t *)nullptr : cnt + k,      \
+        (PRIM) ? (uint32_t)nslots : 0u, cur + k, c->ray_o.as<float4>(), c->ray_d.as<float4>(), c->hits.as<float4>(), c->ovf.as<int>(), ws, \
+        c->refill_min, c->static_eighths, c->leaf_min, g, pix0, np, cnt
+            if (k == 0) {
+                if (count_work) hipLaunchKernelGGL((k_extend<true, true>), MI_EXTEND_ARGS(true));
+                else hipLaunchKernelGGL((k_extend<false, true>), MI_EXTEND_ARGS(true));
+            } else {
+                if (count_work) hipLaunchKernelGGL((k_extend<true, false>), MI_EXTEND_ARGS(false));
+                else hipLaunchKernelGGL((k_extend<false, false>), MI_EXTEND_ARGS(false));
+            }
+#undef MI_EXTEND_ARGS
             if (per_launch) HIPCHK(hipEventRecord(c->ev[evi++], st));
-            hipLaunchKernelGGL(k_shade, dim3(sgrid), dim3(MI_BLOCK), 0, st, c->sc, g, pix0, np, k, p->depth - k, p->seed, qin, cnt + k,
-                               c->ray_o.as<float4>(), c->ray_d.as<float4>(), c->thr.as<float4>(), c->hits.as<float4>(),
-                               c->hist_e.as<float4>(), c->hist_w.as<float4>(), cap, c->path_out.as<float4>(), qout, cnt + k + 1);
+#define MI_SHADE_ARGS                                                                                                          \
+    dim3(sgrid), dim3(MI_BLOCK), 0, st, c->sc, g, pix0, np, k, p->depth - k, p->seed, qin, cnt + k, c->ray_o.as<float4>(),       \
+        c->ray_d.as<float4>(), c->thr.as<float4>(), c->hits.as<float4>(), c->hist_e.as<float4>(), c->hist_w.as<float4>(), cap, \
+        c->path_out.as<float4>(), qout, cnt + k + 1, (uint32_t)nslots
+            if (k == 0) hipLaunchKernelGGL(k_shade<true>, MI_SHADE_ARGS);
+            else hipLaunchKernelGGL(k_shade<false>, MI_SHADE_ARGS);
+#undef MI_SHADE_ARGS
             if (per_launch) HIPCHK(hipEventRecord(c->ev[evi++], st));
         }
         hipLaunchKernelGGL(k_resolve, dim3((np + MI_BLOCK - 1) / MI_BLOCK), dim3(MI_BLOCK), 0, st, g, pix0, np, c->path_out.as<float4>(),
@@ -344,7 +353,7 @@ MI_API mi_status mi_render_device(mi_ctx *c, const mi_render_params *p, void *d_
         hipLaunchKernelGGL(k_sum_counts, dim3(1), dim3(64), 0, st, cnt, levels, c->totals.as<uint64_t>());
     }
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(c->h_totals, c->totals.p, 32, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(c->h_totals, c->totals.p, 64, hipMemcpyDeviceToHost, st));
     HIPCHK(hipEventRecord(c->ev[1], st));
     HIPCHK(hipStreamSynchronize(st));
     if (stats) {
@@ -357,6 +366,9 @@ MI_API mi_status mi_render_device(mi_ctx *c, const mi_render_params *p, void *d_
         stats->batches = (uint32_t)n_batches;
         stats->node_visits = c->h_totals[2];
         stats->prim_tests = c->h_totals[3];
+        if (count_work && getenv("MI_TRACER_DEBUG_LEVELS"))
+            fprintf(stderr, "max node steps of one ray %llu, wave iterations total %llu max %llu\n", (unsigned long long)c->h_totals[4],
+                    (unsigned long long)c->h_totals[5], (unsigned long long)c->h_totals[6]);
         if (per_launch) {
             double me = 0, msh = 0;
             for (size_t i = 2; i + 3 <= evi; i += 3) {
@@ -365,6 +377,18 @@ MI_API mi_status mi_render_device(mi_ctx *c, const mi_render_params *p, void *d_
                 HIPCHK(hipEventElapsedTime(&b2, c->ev[i + 1], c->ev[i + 2]));
                 me += a; msh += b2;
                 stats->extend_launches++;
+            }
+            if (getenv("MI_TRACER_DEBUG_LEVELS")) { // per-launch timings and queue lengths, for tuning only
+                std::vector<uint32_t> hc(kMaxLevels + 1);
+                (void)hipMemcpy(hc.data(), cnt, hc.size() * 4, hipMemcpyDeviceToHost); // counts of the LAST batch
+                size_t j = 2;
+                for (int64_t b = 0; b < n_batches; b++)
+                    for (int k = 0; k < levels; k++, j += 3) {
+                        float a = 0, b2 = 0;
+                        (void)hipEventElapsedTime(&a, c->ev[j], c->ev[j + 1]);
+                        (void)hipEventElapsedTime(&b2, c->ev[j + 1], c->ev[j + 2]);
+                        fprintf(stderr, "batch %lld level %d rays %u extend %.3f ms shade %.3f ms\n", (long long)b, k, b == n_batches - 1 ? hc[k] : 0u, a, b2);
+                    }
             }
             stats->ms_extend = me;
             stats->ms_shade = msh;
@@ -432,9 +456,10 @@ static mi_status probe_chunk(mi_ctx *c, int64_t n, int32_t *prim_id_out, float *
     hipStream_t st = c->stream;
     uint32_t *cur = c->counters.as<uint32_t>();
     HIPCHK(hipMemsetAsync(cur, 0, 4, st));
-    hipLaunchKernelGGL(k_extend<false>, dim3(extend_grid(c)), dim3(MI_BLOCK), 0, st, c->sc, (const uint32_t *)nullptr, (const uint32_t *)nullptr,
-                       (uint32_t)n, cur, c->ray_o.as<float4>(), c->ray_d.as<float4>(), c->hits.as<float4>(), c->ovf.as<int>(),
-                       (unsigned long long *)nullptr, c->refill_min, c->static_eighths, c->leaf_min);
+    hipLaunchKernelGGL((k_extend<false, false>), dim3(extend_grid(c)), dim3(MI_BLOCK), 0, st, c->sc, (const uint32_t *)nullptr,
+                       (const uint32_t *)nullptr, (uint32_t)n, cur, c->ray_o.as<float4>(), c->ray_d.as<float4>(), c->hits.as<float4>(),
+                       c->ovf.as<int>(), (unsigned long long *)nullptr, c->refill_min, c->static_eighths, c->leaf_min, ShardGeom{}, 0u, 1u,
+                       (uint32_t *)nullptr);
     hipLaunchKernelGGL(k_probe_out, dim3((unsigned)((n + MI_BLOCK - 1) / MI_BLOCK)), dim3(MI_BLOCK), 0, st, c->sc, n, c->ray_o.as<float4>(),
                        c->ray_d.as<float4>(), c->hits.as<float4>(), c->probe_i.as<int32_t>(), c->probe_t.as<float>(),
                        n_out ? c->probe_n.as<float>() : nullptr);
