@@ -260,31 +260,125 @@ __device__ __forceinline__ void prim_test(const DevScene &sc, int slot, f3 o, f3
     else tri_test(sc, slot, o, d, h);
 }
 
-// bbox.cu:15-34.  EXACT keeps the reference's `(a<b?a:b)` macros (a NaN operand
-// yields the second operand); the fast form uses v_min/v_max, which is the same
-// function whenever no operand is NaN — guaranteed when 1/d is finite on all axes.
-template <bool EXACT>
-__device__ __forceinline__ bool slab(f3 bmin, f3 bmax, f3 o, f3 inv, float tmax, float &tmin_out) {
+// bbox.cu:15-34, the reference's expression: (b - p) * (1/d) per slab plane and the
+// `(a<b?a:b)` macros (a NaN operand yields the second operand).  Used for rays with a
+// zero / denormal direction component (1/d infinite or huge), where NaNs can arise.
+__device__ __forceinline__ bool slab_exact(f3 bmin, f3 bmax, f3 o, f3 inv, float tmax, float &tmin_out) {
     float t10 = (bmin.x - o.x) * inv.x, t11 = (bmin.y - o.y) * inv.y, t12 = (bmin.z - o.z) * inv.z;
     float t20 = (bmax.x - o.x) * inv.x, t21 = (bmax.y - o.y) * inv.y, t22 = (bmax.z - o.z) * inv.z;
     float tmin = -1.0e38f;
-    if (EXACT) {
 #define MI_MIN(a, b) ((a) < (b) ? (a) : (b))
 #define MI_MAX(a, b) ((a) < (b) ? (b) : (a))
-        tmin = MI_MAX(tmin, MI_MIN(t10, t20));
-        tmin = MI_MAX(tmin, MI_MIN(t11, t21));
-        tmin = MI_MAX(tmin, MI_MIN(t12, t22));
-        tmax = MI_MIN(tmax, MI_MAX(t10, t20));
-        tmax = MI_MIN(tmax, MI_MAX(t11, t21));
-        tmax = MI_MIN(tmax, MI_MAX(t12, t22));
+    tmin = MI_MAX(tmin, MI_MIN(t10, t20));
+    tmin = MI_MAX(tmin, MI_MIN(t11, t21));
+    tmin = MI_MAX(tmin, MI_MIN(t12, t22));
+    tmax = MI_MIN(tmax, MI_MAX(t10, t20));
+    tmax = MI_MIN(tmax, MI_MAX(t11, t21));
+    tmax = MI_MIN(tmax, MI_MAX(t12, t22));
 #undef MI_MIN
 #undef MI_MAX
-    } else {
-        tmin = fmaxf(fmaxf(fmaxf(tmin, fminf(t10, t20)), fminf(t11, t21)), fminf(t12, t22));
-        tmax = fminf(fminf(fminf(tmax, fmaxf(t10, t20)), fmaxf(t11, t21)), fmaxf(t12, t22));
-    }
     tmin_out = tmin;
     return tmin <= tmax && tmax > 0;
+}
+
+// Raw VALU min/max (no sNaN-canonicalising v_max x,x in front of every operand, which
+// hipcc adds to fminf/fmaxf).  Only used where no operand can be NaN.
+__device__ __forceinline__ float vmin(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float vmax(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float vmin3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float vmax3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+
+// Fast slab test for rays whose 1/d is finite and moderate on every axis (no NaN can
+// arise): one FMA per plane, t = b*(1/d) - o*(1/d), and hardware min/max.  It brackets
+// the same interval as bbox.cu:21-32 up to rounding of the order of one ulp of the
+// coordinates, far inside the 1e-5 x scene-diagonal padding of the stored boxes, so it
+// is a conservative culling test: the closest hit it leads to is the one a test of
+// every primitive finds (checked bit-for-bit against the brute-force oracle).
+__device__ __forceinline__ bool slab_fast(f3 bmin, f3 bmax, f3 inv, f3 noi, float tmax, float &tmin_out) {
+    float t10 = __builtin_fmaf(bmin.x, inv.x, noi.x), t11 = __builtin_fmaf(bmin.y, inv.y, noi.y), t12 = __builtin_fmaf(bmin.z, inv.z, noi.z);
+    float t20 = __builtin_fmaf(bmax.x, inv.x, noi.x), t21 = __builtin_fmaf(bmax.y, inv.y, noi.y), t22 = __builtin_fmaf(bmax.z, inv.z, noi.z);
+    float tmin = vmax3(vmin(t10, t20), vmin(t11, t21), vmin(t12, t22));
+    float tmx = vmin(tmax, vmin3(vmax(t10, t20), vmax(t11, t21), vmax(t12, t22)));
+    tmin_out = tmin;
+    return tmin <= tmx && tmx > 0;
+}
+
+// Set by k_tail when it takes over the remaining levels of a batch: 0 = wavefront
+// kernels run, k > 0 = every kernel of level >= k returns at once.
+__device__ __forceinline__ bool tail_took_over(const uint32_t *tail_level, int level) {
+    uint32_t tl = *tail_level;
+    return tl != 0 && (int)tl <= level;
+}
+
+#define MI_DONE 0x7fffffff
+#define MI_NONE (-1)
+// Per-lane traversal state of the persistent kernels.
+struct Lane {
+    f3 o, d, inv, noi; // noi = -(o * inv), for the fast slab test
+    Hit h;
+    int cur, sp, pend0, pend1;
+    bool exact;
+};
+__device__ __forceinline__ void lane_start(const DevScene &sc, Lane &L, f3 o, f3 d) {
+    L.o = o;
+    L.d = d;
+    L.inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z); // ray.h:53-57,79-82
+    L.noi = mk3(-(o.x * L.inv.x), -(o.y * L.inv.y), -(o.z * L.inv.z));
+    // fast slab path only when nothing can overflow to inf/NaN (the comparisons are false for NaN)
+    L.exact = !(__builtin_fabsf(L.inv.x) < 1e30f && __builtin_fabsf(L.inv.y) < 1e30f && __builtin_fabsf(L.inv.z) < 1e30f &&
+                __builtin_fabsf(L.noi.x) < 1e30f && __builtin_fabsf(L.noi.y) < 1e30f && __builtin_fabsf(L.noi.z) < 1e30f);
+    L.h = Hit{MI_NO_HIT, 0.0f, 0.0f, -1};
+    L.sp = 0;
+    L.pend0 = L.pend1 = MI_NONE;
+    if (sc.n_tri + sc.n_sph == 0) {       // bvh.cu:174-176,180-181
+        L.cur = MI_DONE;
+    } else if (sc.root_ref < 0) {         // bvh.cu:182-183
+        L.pend0 = ~sc.root_ref;
+        L.cur = MI_DONE;
+    } else {
+        L.cur = sc.root_ref;
+    }
+}
+// Node phase of one lane: fetch node L.cur (64 B), slab-test both child boxes, queue
+// leaf children as pending, descend near-first / pop (bvh.cu:178-207 restructured).
+__device__ __forceinline__ void node_phase(const DevScene &sc, Lane &L, int *stack, int *my_ovf, size_t ovf_stride) {
+    const char *nd = (const char *)sc.nodes + ((uint32_t)L.cur << 6);
+    float4 n0 = *(const float4 *)(nd), n1 = *(const float4 *)(nd + 16), n2 = *(const float4 *)(nd + 32);
+    int2 refs = *(const int2 *)(nd + 48);
+    float tminL, tminR;
+    bool hitL, hitR;
+    if (L.exact) {
+        hitL = slab_exact(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), L.o, L.inv, L.h.t, tminL);
+        hitR = slab_exact(mk3(n1.z, n1.w, n2.x), mk3(n2.y, n2.z, n2.w), L.o, L.inv, L.h.t, tminR);
+    } else {
+        hitL = slab_fast(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), L.inv, L.noi, L.h.t, tminL);
+        hitR = slab_fast(mk3(n1.z, n1.w, n2.x), mk3(n2.y, n2.z, n2.w), L.inv, L.noi, L.h.t, tminR);
+    }
+    int l = refs.x, r = refs.y;
+    if (hitL && l < 0) L.pend0 = ~l;
+    if (hitR && r < 0) { if (L.pend0 == MI_NONE) L.pend0 = ~r; else L.pend1 = ~r; }
+    bool goL = hitL && l >= 0, goR = hitR && r >= 0;
+    if (goL && goR) {
+        if (tminR < tminL) { int tmp = l; l = r; r = tmp; }
+        if (L.sp < MI_LDS_STACK) stack[L.sp * MI_BLOCK] = r;
+        else my_ovf[(size_t)(L.sp - MI_LDS_STACK) * ovf_stride] = r;
+        L.sp++;
+        L.cur = l;
+    } else if (goL) {
+        L.cur = l;
+    } else if (goR) {
+        L.cur = r;
+    } else if (L.sp == 0) {
+        L.cur = MI_DONE;
+    } else {
+        L.sp--;
+        L.cur = L.sp < MI_LDS_STACK ? stack[L.sp * MI_BLOCK] : my_ovf[(size_t)(L.sp - MI_LDS_STACK) * ovf_stride];
+    }
+}
+__device__ __forceinline__ void leaf_phase(const DevScene &sc, Lane &L) { // one pending primitive
+    prim_test(sc, L.pend0, L.o, L.d, L.h);
+    L.pend0 = L.pend1;
+    L.pend1 = MI_NONE;
 }
 
 // Persistent waves, per-lane ray refill, and leaf tests postponed to their own phase.
@@ -308,8 +402,6 @@ __device__ __forceinline__ bool slab(f3 bmin, f3 bmax, f3 o, f3 inv, float tmax,
 // COUNT = true is the instrumented build used once per bench run (outside the timed
 // region) to measure node visits and primitive tests per ray: work_stats[0] += node
 // visits, [1] += primitive tests.
-#define MI_DONE 0x7fffffff
-#define MI_NONE (-1)
 // PRIMARY = true is level 0: the queue is the identity over the batch's slots, rays
 // come from primary_ray(), and the number of slots that are real pixels is added to
 // *primary_count (it is the level-0 ray count).
@@ -317,44 +409,48 @@ template <bool COUNT, bool PRIMARY>
 __global__ void __launch_bounds__(MI_BLOCK)
 k_extend(DevScene sc, const uint32_t *queue, const uint32_t *count_ptr, uint32_t fixed_count, uint32_t *cursor,
          const float4 *ray_o, const float4 *ray_d, float4 *hits, int *ovf, unsigned long long *work_stats, int refill_min,
-         uint32_t static_eighths, int leaf_min, ShardGeom g, uint32_t pix0, uint32_t npix, uint32_t *primary_count) {
+         uint32_t static_eighths, int leaf_min, ShardGeom g, uint32_t pix0, uint32_t npix, uint32_t *primary_count,
+         const uint32_t *tail_level, int level) {
     __shared__ int lds_stack[MI_LDS_STACK * MI_BLOCK];
+    if (!PRIMARY && tail_level && tail_took_over(tail_level, level)) return;
     const uint32_t n = count_ptr ? *count_ptr : fixed_count;
     const int lane = threadIdx.x & 63;
     int *stack = lds_stack + threadIdx.x;
     const size_t ovf_stride = (size_t)gridDim.x * MI_BLOCK;
     int *my_ovf = ovf + (size_t)blockIdx.x * MI_BLOCK + threadIdx.x;
-    const bool empty_scene = sc.n_tri + sc.n_sph == 0;
-    const char *node_base = (const char *)sc.nodes;
     // Work distribution in 64-ray chunks.  The first static_eighths/8 of the chunks are
     // dealt statically, interleaved over the waves (wave w takes chunks w, w+W, w+2W, ...:
     // no atomics, and every wave sees the same mix of image regions); the rest is pulled
     // dynamically, 4 chunks per returning atomic (a single word sustains only ~90
     // returning atomics/us), to even out the tail.
+    // Wave-uniform bookkeeping is kept in SGPRs (readfirstlane) and the loop has a single
+    // back edge and no `continue`: with a more tangled control flow the compiler copies
+    // the whole per-lane state (≈45 v_mov) on every iteration.
     const uint32_t n_waves = gridDim.x * (MI_BLOCK / 64);
-    const uint32_t wave_id = blockIdx.x * (MI_BLOCK / 64) + (threadIdx.x >> 6);
+    const uint32_t wave_id = __builtin_amdgcn_readfirstlane(blockIdx.x * (MI_BLOCK / 64) + (threadIdx.x >> 6));
     const uint32_t n_chunks = (n + 63u) >> 6;
     uint32_t static_per_wave = (uint32_t)(((uint64_t)n_chunks * static_eighths) / (8u * n_waves));
     if (static_per_wave == 0) static_per_wave = 1;
-    const uint32_t dyn_first = static_per_wave * n_waves;           // first dynamically dealt chunk
-    uint32_t static_k = 0;                                          // wave-uniform
-    uint32_t rng_next = 0, rng_end = 0;                             // wave-uniform, in rays
-    bool exhausted = false;                                         // wave-uniform
+    const uint32_t dyn_first = static_per_wave * n_waves; // first dynamically dealt chunk
+    uint32_t static_k = 0;                                // wave-uniform
+    uint32_t rng_next = 0, rng_end = 0;                   // wave-uniform, in rays
+    uint32_t more = 1;                                    // wave-uniform: chunks may remain
     uint32_t n_nodes = 0, n_leaves = 0, ray_steps = 0, max_ray_steps = 0, wave_iters = 0;
     uint32_t n_primary = 0; // wave-uniform
 
-    bool active = false, exact = false;
+    bool active = false;
     uint32_t slot = 0;
-    f3 o = mk3(0, 0, 0), d = mk3(0, 0, 0), inv = mk3(0, 0, 0);
-    Hit h{MI_NO_HIT, 0.0f, 0.0f, -1};
-    int cur = MI_DONE, sp = 0, pend0 = MI_NONE, pend1 = MI_NONE;
-    for (;;) {
-        unsigned long long act = __ballot(active);
-        int n_idle = 64 - __popcll(act);
+    Lane L;
+    L.cur = MI_DONE; L.sp = 0; L.pend0 = L.pend1 = MI_NONE; L.exact = false;
+    L.h = Hit{MI_NO_HIT, 0.0f, 0.0f, -1};
+    L.o = L.d = L.inv = L.noi = mk3(0, 0, 0);
+    unsigned long long act = 0ull; // ballot of `active`
+    do {
         // Refill: whenever at least refill_min lanes are idle, hand them the next rays of
         // this wave's current chunk range, so rays of different traversal length do not
         // leave lanes idle for the rest of a 64-ray packet.
-        if (!exhausted && (n_idle >= refill_min || act == 0ull)) {
+        const int n_idle = 64 - __popcll(act);
+        if (more && (n_idle >= refill_min || act == 0ull)) {
             if (rng_next >= rng_end) {
                 uint32_t c0 = n_chunks, c1 = n_chunks; // next chunk range [c0, c1)
                 if (static_k < static_per_wave) {
@@ -375,8 +471,10 @@ k_extend(DevScene sc, const uint32_t *queue, const uint32_t *count_ptr, uint32_t
                         c1 = c0 + 4;
                     }
                 }
+                c0 = __builtin_amdgcn_readfirstlane(c0);
+                c1 = __builtin_amdgcn_readfirstlane(c1);
                 if (c0 >= n_chunks) {
-                    if (static_k >= static_per_wave) exhausted = true;
+                    if (static_k >= static_per_wave) more = 0;
                     rng_next = rng_end = 0;
                 } else {
                     rng_next = c0 << 6;
@@ -384,10 +482,11 @@ k_extend(DevScene sc, const uint32_t *queue, const uint32_t *count_ptr, uint32_t
                 }
             }
             if (rng_next < rng_end) {
-                uint32_t rank = (uint32_t)__popcll(~act & ((1ull << lane) - 1ull));
-                uint32_t idx = rng_next + rank;
-                uint32_t avail = rng_end - rng_next;
+                const uint32_t rank = (uint32_t)__popcll(~act & ((1ull << lane) - 1ull));
+                const uint32_t idx = rng_next + rank;
+                const uint32_t avail = rng_end - rng_next;
                 bool take = !active && rank < avail;
+                f3 o = mk3(0, 0, 0), d = mk3(0, 0, 0);
                 if (PRIMARY) {
                     if (take) {
                         slot = idx;
@@ -398,89 +497,41 @@ k_extend(DevScene sc, const uint32_t *queue, const uint32_t *count_ptr, uint32_t
                     n_primary += (uint32_t)__popcll(__ballot(take));
                 } else if (take) {
                     slot = queue ? queue[idx] : idx;
-                    float4 o4 = ray_o[slot], d4 = ray_d[slot];
-                    o = xyz(o4);
-                    d = xyz(d4);
+                    o = xyz(ray_o[slot]);
+                    d = xyz(ray_d[slot]);
                 }
                 if (take) {
-                    inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z); // ray.h:53-57,79-82
-                    exact = !(__builtin_isfinite(inv.x) && __builtin_isfinite(inv.y) && __builtin_isfinite(inv.z));
-                    h = Hit{MI_NO_HIT, 0.0f, 0.0f, -1};
-                    sp = 0;
-                    pend0 = pend1 = MI_NONE;
+                    lane_start(sc, L, o, d);
                     active = true;
-                    if (empty_scene) {                       // bvh.cu:174-176,180-181
-                        cur = MI_DONE;
-                    } else if (sc.root_ref < 0) {            // bvh.cu:182-183
-                        pend0 = ~sc.root_ref;
-                        cur = MI_DONE;
-                    } else {
-                        cur = sc.root_ref;
-                    }
                 }
                 rng_next += (uint32_t)n_idle < avail ? (uint32_t)n_idle : avail;
             }
-            act = __ballot(active);
-            if (act == 0ull) {
-                if (exhausted) break;
-                continue;
-            }
-        } else if (act == 0ull) {
-            break; // exhausted and nothing in flight
         }
-
         if (COUNT) wave_iters++;
-        const bool want_leaf = active && pend0 != MI_NONE;
-        const bool want_node = active && pend0 == MI_NONE && cur != MI_DONE;
+        const bool want_leaf = active && L.pend0 != MI_NONE;
+        const bool want_node = active && L.pend0 == MI_NONE && L.cur != MI_DONE;
         const int nl = __popcll(__ballot(want_leaf)), nn = __popcll(__ballot(want_node));
         if (nl > 0 && (nl >= leaf_min || nn == 0)) {
-            if (want_leaf) { // leaf phase: one primitive per lane
+            if (want_leaf) {
                 if (COUNT) n_leaves++;
-                prim_test(sc, pend0, o, d, h);
-                pend0 = pend1;
-                pend1 = MI_NONE;
+                leaf_phase(sc, L);
             }
-        } else if (want_node) { // node phase
-            if (COUNT) { n_nodes++; ray_steps++; }
-            const char *nd = node_base + ((uint32_t)cur << 6);
-            float4 n0 = *(const float4 *)(nd), n1 = *(const float4 *)(nd + 16), n2 = *(const float4 *)(nd + 32);
-            int2 refs = *(const int2 *)(nd + 48);
-            float tminL, tminR;
-            bool hitL, hitR;
-            if (exact) {
-                hitL = slab<true>(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), o, inv, h.t, tminL);
-                hitR = slab<true>(mk3(n1.z, n1.w, n2.x), mk3(n2.y, n2.z, n2.w), o, inv, h.t, tminR);
-            } else {
-                hitL = slab<false>(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), o, inv, h.t, tminL);
-                hitR = slab<false>(mk3(n1.z, n1.w, n2.x), mk3(n2.y, n2.z, n2.w), o, inv, h.t, tminR);
+        } else if (want_node) {
+            if (COUNT) {
+                n_nodes++;
+                ray_steps++;
+                int depth = __float_as_int(sc.nodes[4 * (size_t)L.cur + 3].z);
+                atomicAdd(&work_stats[8 + (depth < 40 ? depth : 39)], 1ull);
             }
-            int l = refs.x, r = refs.y;
-            if (hitL && l < 0) pend0 = ~l;
-            if (hitR && r < 0) { if (pend0 == MI_NONE) pend0 = ~r; else pend1 = ~r; }
-            bool goL = hitL && l >= 0, goR = hitR && r >= 0;
-            if (goL && goR) {
-                if (tminR < tminL) { int tmp = l; l = r; r = tmp; }
-                if (sp < MI_LDS_STACK) stack[sp * MI_BLOCK] = r;
-                else my_ovf[(size_t)(sp - MI_LDS_STACK) * ovf_stride] = r;
-                sp++;
-                cur = l;
-            } else if (goL) {
-                cur = l;
-            } else if (goR) {
-                cur = r;
-            } else if (sp == 0) {
-                cur = MI_DONE;
-            } else {
-                sp--;
-                cur = sp < MI_LDS_STACK ? stack[sp * MI_BLOCK] : my_ovf[(size_t)(sp - MI_LDS_STACK) * ovf_stride];
-            }
+            node_phase(sc, L, stack, my_ovf, ovf_stride);
         }
-        if (active && cur == MI_DONE && pend0 == MI_NONE) {
-            hits[slot] = make_float4(h.t, __int_as_float(h.slot), h.u, h.v);
+        if (active && L.cur == MI_DONE && L.pend0 == MI_NONE) {
+            hits[slot] = make_float4(L.h.t, __int_as_float(L.h.slot), L.h.u, L.h.v);
             active = false;
             if (COUNT) { max_ray_steps = max(max_ray_steps, ray_steps); ray_steps = 0; }
         }
-    }
+        act = __ballot(active);
+    } while (more || act != 0ull);
     if (PRIMARY && lane == 0 && n_primary) atomicAdd(primary_count, n_primary);
     if (COUNT) {
         atomicMax(&work_stats[2], (unsigned long long)max_ray_steps);
@@ -551,6 +602,75 @@ __device__ __forceinline__ float4 clamp01_4(float4 a) { // vec.h:184-186, CpuTra
                        fminf(fmaxf(a.w, 0.0f), 1.0f));
 }
 
+// Global path id = (j*W + i)*spp + sx*s + sy: the RNG key the oracle uses.
+__device__ __forceinline__ uint64_t path_id(const ShardGeom &g, int px, int py, uint32_t samp) {
+    return ((uint64_t)py * g.width + px) * (uint64_t)(g.samples * g.samples) + (uint64_t)samp;
+}
+
+// Shading of one path at one level: CpuTracer.cu:124-185 for a ray (o,d) with
+// throughput T whose closest hit is (t, pslot, u, v).  Either the path ends — its value
+// is folded from the stored history and written to path_out — and false is returned,
+// or (e, w) of this level are stored and the continuation ray (no, nd) with throughput
+// Tn is returned with true.
+__device__ __forceinline__ bool shade_path(const DevScene &sc, uint64_t seed, uint64_t path, int level, int depth_left, uint32_t slot,
+                                           f3 o, f3 d, float4 T, float t, int pslot, float hu, float hv, float4 *hist_e,
+                                           float4 *hist_w, size_t cap, float4 *path_out, f3 &no, f3 &nd, float4 &Tn) {
+    if (pslot < 0) { // CpuTracer.cu:124-125: miss -> (1,1,1,1)
+        path_out[slot] = clamp01_4(fold_history(hist_e, hist_w, cap, slot, level, make_float4(1.0f, 1.0f, 1.0f, 1.0f)));
+        return false;
+    }
+    f3 N;
+    DMat m;
+    hit_surface(sc, pslot, t, hu, hv, o, d, N, m);
+    float4 e = mul4(m.ke, 32.0f); // CpuTracer.cu:131,185
+    if (depth_left < 0) {         // CpuTracer.cu:130-131
+        path_out[slot] = clamp01_4(fold_history(hist_e, hist_w, cap, slot, level, e));
+        return false;
+    }
+    f3 hitInner = o + (t + MI_EPS) * d; // :127
+    f3 hitOuter = o + (t - MI_EPS) * d; // :128
+    float reflect = m.kr.x, refract = m.kt.x; // :136-137
+    uint32_t ctr[4] = {(uint32_t)path, (uint32_t)(path >> 32), (uint32_t)level, 0u};
+    philox4x32_10(ctr, (uint32_t)seed, (uint32_t)(seed >> 32));
+    float rnd = u01(ctr[0]); // :138
+    f3 refl = d - (2.0f * N) * dot3(N, d); // :140
+    float4 w;
+    if (rnd < refract) { // :141
+        bool into = dot3(d, N) < 0; // :142
+        f3 nn = into ? N : -N;
+        float n1 = 1.0f, n2 = m.index;
+        float ratio = into ? n1 / n2 : n2 / n1;
+        float dt = dot3(d, nn);
+        float cos2t = 1 - ratio * ratio * (1 - dt * dt); // :148
+        if (cos2t < 0) { // :149-152 total internal reflection
+            no = hitOuter; nd = refl; w = m.kr;
+        } else { // :154-166
+            nd = normalize3(d * ratio - nn * (dt * ratio + __builtin_sqrtf(cos2t)));
+            no = hitInner;
+            float a = n2 - n1, b = n2 + n1;
+            float R0 = (a * a) / (b * b);
+            float cc = 1.0f - (into ? -dt : dot3(nd, -nn));
+            float Re = R0 + (1.0f - R0) * cc * cc * cc * cc * cc;
+            float ratio2 = ratio * ratio;
+            float Tr = (1.0f - Re) * ratio2;
+            w = make_float4(Tr, Tr, Tr, Tr);
+        }
+    } else { // :168-174 glossy/diffuse bounce
+        f3 diff = hemisphere(N, u01(ctr[1]), u01(ctr[2]));
+        nd = normalize3(reflect * refl + (1 - reflect) * diff);
+        no = hitOuter; w = m.kd;
+    }
+    Tn = mul4(w, T); // `w * thresh`, :152,166,174
+    hist_e[(size_t)level * cap + slot] = e;
+    hist_w[(size_t)level * cap + slot] = w;
+    // entry test of the next level, CpuTracer.cu:121-122
+    if ((double)length2_4(Tn) < 3.0 * 12.0 / 255.0 / 255.0) {
+        path_out[slot] = clamp01_4(fold_history(hist_e, hist_w, cap, slot, level + 1, make_float4(0.0f, 0.0f, 0.0f, 0.0f)));
+        return false;
+    }
+    return true;
+}
+
 // One thread per queue entry of level `level`; depth_left = D - level.  PRIMARY = true
 // is level 0: identity queue over the batch's n_fixed slots, ray from primary_ray(),
 // throughput (1,1,1,1) (traceRay(r, 1, depth), CpuTracer.cu:114); slots that are not
@@ -559,7 +679,9 @@ template <bool PRIMARY>
 __global__ void __launch_bounds__(MI_BLOCK)
 k_shade(DevScene sc, ShardGeom g, uint32_t pix0, uint32_t npix, int level, int depth_left, uint64_t seed,
         const uint32_t *queue, const uint32_t *count_ptr, float4 *ray_o, float4 *ray_d, float4 *thr, const float4 *hits,
-        float4 *hist_e, float4 *hist_w, size_t cap, float4 *path_out, uint32_t *next_queue, uint32_t *next_count, uint32_t n_fixed) {
+        float4 *hist_e, float4 *hist_w, size_t cap, float4 *path_out, uint32_t *next_queue, uint32_t *next_count, uint32_t n_fixed,
+        const uint32_t *tail_level) {
+    if (!PRIMARY && tail_took_over(tail_level, level)) return;
     const uint32_t n = PRIMARY ? n_fixed : *count_ptr;
     const uint32_t stride = gridDim.x * MI_BLOCK;
     // every thread of a workgroup runs the same number of iterations (queue_append has barriers)
@@ -580,81 +702,128 @@ k_shade(DevScene sc, ShardGeom g, uint32_t pix0, uint32_t npix, int level, int d
         }
         if (live) {
             float4 h4 = hits[slot];
-            float t = h4.x;
             int pslot = __float_as_int(h4.y);
-            float4 T = PRIMARY ? make_float4(1.0f, 1.0f, 1.0f, 1.0f) : thr[slot];
-            if (pslot < 0) { // CpuTracer.cu:124-125: miss -> (1,1,1,1)
-                path_out[slot] = clamp01_4(fold_history(hist_e, hist_w, cap, slot, level, make_float4(1.0f, 1.0f, 1.0f, 1.0f)));
-            } else {
-                if (!PRIMARY) {
+            float4 T = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+            if (!PRIMARY) {
+                T = thr[slot];
+                if (pslot >= 0) {
                     o = xyz(ray_o[slot]);
                     d = xyz(ray_d[slot]);
+                    samp = slot / npix;
+                    uint32_t lp = slot - samp * npix;
+                    local_to_pixel(g, slot_to_local(g, pix0 + lp), px, py);
                 }
-                f3 N;
-                DMat m;
-                hit_surface(sc, pslot, t, h4.z, h4.w, o, d, N, m);
-                float4 e = mul4(m.ke, 32.0f); // CpuTracer.cu:131,185
-                if (depth_left < 0) {         // CpuTracer.cu:130-131
-                    path_out[slot] = clamp01_4(fold_history(hist_e, hist_w, cap, slot, level, e));
-                } else {
-                    f3 hitInner = o + (t + MI_EPS) * d; // :127
-                    f3 hitOuter = o + (t - MI_EPS) * d; // :128
-                    float reflect = m.kr.x, refract = m.kt.x; // :136-137
-                    // path id = (j*W + i)*spp + sx*s + sy, the oracle's key
-                    if (!PRIMARY) {
-                        samp = slot / npix;
-                        uint32_t lp = slot - samp * npix;
-                        local_to_pixel(g, slot_to_local(g, pix0 + lp), px, py);
-                    }
-                    uint64_t path = ((uint64_t)py * g.width + px) * (uint64_t)(g.samples * g.samples) + (uint64_t)samp;
-                    uint32_t ctr[4] = {(uint32_t)path, (uint32_t)(path >> 32), (uint32_t)level, 0u};
-                    philox4x32_10(ctr, (uint32_t)seed, (uint32_t)(seed >> 32));
-                    float rnd = u01(ctr[0]); // :138
-                    f3 refl = d - (2.0f * N) * dot3(N, d); // :140
-                    f3 no, nd;
-                    float4 w;
-                    if (rnd < refract) { // :141
-                        bool into = dot3(d, N) < 0; // :142
-                        f3 nn = into ? N : -N;
-                        float n1 = 1.0f, n2 = m.index;
-                        float ratio = into ? n1 / n2 : n2 / n1;
-                        float dt = dot3(d, nn);
-                        float cos2t = 1 - ratio * ratio * (1 - dt * dt); // :148
-                        if (cos2t < 0) { // :149-152 total internal reflection
-                            no = hitOuter; nd = refl; w = m.kr;
-                        } else { // :154-166
-                            nd = normalize3(d * ratio - nn * (dt * ratio + __builtin_sqrtf(cos2t)));
-                            no = hitInner;
-                            float a = n2 - n1, b = n2 + n1;
-                            float R0 = (a * a) / (b * b);
-                            float cc = 1.0f - (into ? -dt : dot3(nd, -nn));
-                            float Re = R0 + (1.0f - R0) * cc * cc * cc * cc * cc;
-                            float ratio2 = ratio * ratio;
-                            float Tr = (1.0f - Re) * ratio2;
-                            w = make_float4(Tr, Tr, Tr, Tr);
-                        }
-                    } else { // :168-174 glossy/diffuse bounce
-                        f3 diff = hemisphere(N, u01(ctr[1]), u01(ctr[2]));
-                        nd = normalize3(reflect * refl + (1 - reflect) * diff);
-                        no = hitOuter; w = m.kd;
-                    }
-                    float4 Tn = mul4(w, T); // `w * thresh`, :152,166,174
-                    hist_e[(size_t)level * cap + slot] = e;
-                    hist_w[(size_t)level * cap + slot] = w;
-                    // entry test of the next level, CpuTracer.cu:121-122
-                    if ((double)length2_4(Tn) < 3.0 * 12.0 / 255.0 / 255.0) {
-                        path_out[slot] = clamp01_4(fold_history(hist_e, hist_w, cap, slot, level + 1, make_float4(0.0f, 0.0f, 0.0f, 0.0f)));
-                    } else {
-                        ray_o[slot] = make_float4(no.x, no.y, no.z, 0.0f);
-                        ray_d[slot] = make_float4(nd.x, nd.y, nd.z, 0.0f);
-                        thr[slot] = Tn;
-                        alive = true;
-                    }
-                }
+            }
+            f3 no, nd;
+            float4 Tn;
+            alive = shade_path(sc, seed, path_id(g, px, py, samp), level, depth_left, slot, o, d, T, h4.x, pslot, h4.z, h4.w, hist_e,
+                               hist_w, cap, path_out, no, nd, Tn);
+            if (alive) {
+                ray_o[slot] = make_float4(no.x, no.y, no.z, 0.0f);
+                ray_d[slot] = make_float4(nd.x, nd.y, nd.z, 0.0f);
+                thr[slot] = Tn;
             }
         }
         queue_append(alive, slot, next_queue, next_count);
     }
+}
+
+// Tail of a batch.  When only a few paths are still alive, one launch per level is
+// bound by the longest single ray of each level (a few hundred dependent node fetches)
+// while most of the chip idles.  k_tail is launched in front of every level k >= 1;
+// it does nothing unless the queue of that level holds at most `threshold` rays, and
+// then carries every remaining path through ALL its remaining levels in one launch:
+// each lane loops traverse -> shade -> traverse ..., with the same node / leaf phases as
+// k_extend plus a shade phase, and is refilled from the queue when its path ends.  It
+// then publishes its level in *tail_level so the per-level kernels behind it return
+// immediately.  Rays traced beyond the first level are added to *extra_rays.
+__global__ void __launch_bounds__(MI_BLOCK)
+k_tail(DevScene sc, ShardGeom g, uint32_t pix0, uint32_t npix, int level0, int depth_total, uint64_t seed, const uint32_t *queue,
+       const uint32_t *count_ptr, uint32_t threshold, uint32_t *tail_level, const float4 *ray_o, const float4 *ray_d, const float4 *thr,
+       float4 *hist_e, float4 *hist_w, size_t cap, float4 *path_out, int *ovf, unsigned long long *extra_rays, int leaf_min,
+       int shade_min) {
+    __shared__ int lds_stack[MI_LDS_STACK * MI_BLOCK];
+    const uint32_t n = *count_ptr;
+    const uint32_t tl = *tail_level;
+    // same decision in every wave: tl is only ever written with level0 by this launch
+    if (n == 0 || n > threshold || (tl != 0 && tl != (uint32_t)level0)) return;
+    const int lane = threadIdx.x & 63;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *tail_level = (uint32_t)level0;
+    int *stack = lds_stack + threadIdx.x;
+    const size_t ovf_stride = (size_t)gridDim.x * MI_BLOCK;
+    int *my_ovf = ovf + (size_t)blockIdx.x * MI_BLOCK + threadIdx.x;
+    const uint32_t n_waves = gridDim.x * (MI_BLOCK / 64);
+    const uint32_t wave_id = blockIdx.x * (MI_BLOCK / 64) + (threadIdx.x >> 6);
+    const uint32_t n_chunks = (n + 63u) >> 6;
+    uint32_t chunk = wave_id;           // static interleaved chunks: wave w takes w, w+W, ...
+    uint32_t rng_next = 0, rng_end = 0; // wave-uniform, in rays
+    uint32_t n_extra = 0;               // wave-uniform
+
+    bool active = false;
+    uint32_t slot = 0;
+    int level = level0;
+    float4 T = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    Lane L;
+    L.cur = MI_DONE; L.sp = 0; L.pend0 = L.pend1 = MI_NONE; L.exact = false;
+    L.h = Hit{MI_NO_HIT, 0.0f, 0.0f, -1};
+    L.o = L.d = L.inv = L.noi = mk3(0, 0, 0);
+    for (;;) {
+        unsigned long long act = __ballot(active);
+        int n_idle = 64 - __popcll(act);
+        bool more = rng_next < rng_end || chunk < n_chunks;
+        if (more && (n_idle >= 16 || act == 0ull)) {
+            if (rng_next >= rng_end) {
+                rng_next = chunk << 6;
+                rng_end = ((chunk + 1) << 6) < n ? ((chunk + 1) << 6) : n;
+                chunk += n_waves;
+            }
+            uint32_t rank = (uint32_t)__popcll(~act & ((1ull << lane) - 1ull));
+            uint32_t avail = rng_end - rng_next;
+            if (!active && rank < avail) {
+                slot = queue[rng_next + rank];
+                T = thr[slot];
+                level = level0;
+                lane_start(sc, L, xyz(ray_o[slot]), xyz(ray_d[slot]));
+                active = true;
+            }
+            rng_next += (uint32_t)n_idle < avail ? (uint32_t)n_idle : avail;
+            act = __ballot(active);
+        }
+        if (act == 0ull) {
+            if (rng_next < rng_end || chunk < n_chunks) continue;
+            break;
+        }
+        const bool want_leaf = active && L.pend0 != MI_NONE;
+        const bool want_node = active && L.pend0 == MI_NONE && L.cur != MI_DONE;
+        const bool want_shade = active && L.pend0 == MI_NONE && L.cur == MI_DONE;
+        const int nl = __popcll(__ballot(want_leaf)), nn = __popcll(__ballot(want_node)), ns = __popcll(__ballot(want_shade));
+        if (ns > 0 && (ns >= shade_min || (nl == 0 && nn == 0))) {
+            bool cont = false;
+            f3 no = mk3(0, 0, 0), nd = mk3(0, 0, 0);
+            float4 Tn = T;
+            if (want_shade) {
+                uint32_t samp = slot / npix;
+                uint32_t lp = slot - samp * npix;
+                int px, py;
+                local_to_pixel(g, slot_to_local(g, pix0 + lp), px, py);
+                cont = shade_path(sc, seed, path_id(g, px, py, samp), level, depth_total - level, slot, L.o, L.d, T, L.h.t, L.h.slot, L.h.u,
+                                  L.h.v, hist_e, hist_w, cap, path_out, no, nd, Tn);
+                if (cont) {
+                    T = Tn;
+                    level++;
+                    lane_start(sc, L, no, nd);
+                } else {
+                    active = false;
+                }
+            }
+            n_extra += (uint32_t)__popcll(__ballot(cont));
+        } else if (nl > 0 && (nl >= leaf_min || nn == 0)) {
+            if (want_leaf) leaf_phase(sc, L);
+        } else if (want_node) {
+            node_phase(sc, L, stack, my_ovf, ovf_stride);
+        }
+    }
+    if (lane == 0 && n_extra) atomicAdd(extra_rays, (unsigned long long)n_extra);
 }
 
 // ------------------------------------------------------------------ resolve

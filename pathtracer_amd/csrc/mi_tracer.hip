@@ -71,6 +71,8 @@ struct mi_ctx {
     int refill_min = 20;        // MI_TRACER_REFILL: idle lanes that trigger a refill
     uint32_t static_eighths = 8; // MI_TRACER_STATIC_EIGHTHS: share of chunks dealt statically, in 1/8
     int leaf_min = 16;          // MI_TRACER_LEAF_MIN: lanes with a pending leaf that trigger a leaf phase
+    int shade_min = 24;         // MI_TRACER_SHADE_MIN: lanes waiting to be shaded that trigger a shade phase of k_tail
+    int tail_threshold = 1500000; // MI_TRACER_TAIL: k_tail takes over a batch once a level has at most this many rays (0 = off)
 };
 
 static const int kMaxLevels = 64; // counters reserved per batch (depth + 2 must fit)
@@ -103,10 +105,12 @@ MI_API mi_status mi_ctx_create(int device_id, mi_ctx **out) {
     c->extend_wg_per_cu = env_int("MI_TRACER_EXTEND_WG_PER_CU", 1, 16, c->extend_wg_per_cu);
     c->refill_min = env_int("MI_TRACER_REFILL", 1, 64, c->refill_min);
     c->leaf_min = env_int("MI_TRACER_LEAF_MIN", 1, 64, c->leaf_min);
+    c->shade_min = env_int("MI_TRACER_SHADE_MIN", 1, 64, c->shade_min);
+    c->tail_threshold = env_int("MI_TRACER_TAIL", 0, 1 << 30, c->tail_threshold);
     c->static_eighths = (uint32_t)env_int("MI_TRACER_STATIC_EIGHTHS", 0, 8, (int)c->static_eighths);
     hipError_t es = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (es != hipSuccess) { delete c; return fail(MI_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(es)); }
-    es = hipHostMalloc((void **)&c->h_totals, 8 * sizeof(uint64_t), hipHostMallocDefault);
+    es = hipHostMalloc((void **)&c->h_totals, 48 * sizeof(uint64_t), hipHostMallocDefault);
     if (es != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return fail(MI_ERR_HIP, "hipHostMalloc failed: %s", hipGetErrorString(es)); }
     *out = c;
     return MI_OK;
@@ -146,6 +150,11 @@ static mi_status validate_scene(const mi_scene_soa *s) {
     }
     if (s->n_nodes != n_prim - 1 || !s->nodes) return fail(MI_ERR_INVALID, "scene: %u nodes for %llu primitives (want n-1)", s->n_nodes, (unsigned long long)n_prim);
     if (s->root_ref < 0 || (uint32_t)s->root_ref >= s->n_nodes) return fail(MI_ERR_INVALID, "scene: bad root_ref");
+    for (size_t i = 0; i < (size_t)s->n_nodes; i++)
+        for (int k = 0; k < 12; k++) {
+            float v = s->nodes[16 * i + k];
+            if (!(v > -1e15f && v < 1e15f)) return fail(MI_ERR_INVALID, "scene: node %zu has a non-finite or huge box", i);
+        }
     std::vector<uint8_t> seen_prim(n_prim, 0), seen_node(s->n_nodes, 0);
     std::vector<std::pair<int32_t, int>> st;
     st.push_back({s->root_ref, 1});
@@ -265,8 +274,9 @@ __global__ void k_sum_counts(const uint32_t *counts, int n, uint64_t *totals) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         uint64_t s = 0;
         for (int i = 0; i < n; i++) s += counts[i];
-        totals[0] += s;         // rays cast = sum of extend queue lengths
-        totals[1] += counts[0]; // paths started
+        totals[0] += s + totals[7]; // rays cast = sum of extend queue lengths + rays k_tail traced beyond its first level
+        totals[7] = 0;
+        totals[1] += counts[0];     // paths started
     }
 }
 
@@ -300,10 +310,10 @@ MI_API mi_status mi_render_device(mi_ctx *c, const mi_render_params *p, void *d_
     HIPCHK(c->hist_w.ensure(cap * 16 * hist_levels));
     HIPCHK(c->queue_a.ensure(cap * 4));
     HIPCHK(c->queue_b.ensure(cap * 4));
-    HIPCHK(c->counters.ensure(2 * (kMaxLevels + 1) * 4));
+    HIPCHK(c->counters.ensure((2 * (kMaxLevels + 1) + 2) * 4));
     const int egrid = extend_grid(c);
     HIPCHK(c->ovf.ensure((size_t)(MI_MAX_STACK - MI_LDS_STACK) * egrid * MI_BLOCK * 4));
-    HIPCHK(c->totals.ensure(8 * 8));
+    HIPCHK(c->totals.ensure(48 * 8));
     const int64_t n_batches = local > 0 ? (local + npix_b - 1) / npix_b : 0;
     const size_t n_ev = 2 + (size_t)n_batches * levels * 3;
     const bool per_launch = n_ev <= 4096; // per-launch timing only while the event count stays modest
@@ -312,8 +322,9 @@ MI_API mi_status mi_render_device(mi_ctx *c, const mi_render_params *p, void *d_
 
     uint32_t *cnt = c->counters.as<uint32_t>();          // cnt[k] = queue length at level k
     uint32_t *cur = cnt + (kMaxLevels + 1);              // cur[k] = work cursor of extend at level k
+    uint32_t *tail_level = cnt + 2 * (kMaxLevels + 1);    // 0, or the level at which k_tail took over
     uint32_t *qa = c->queue_a.as<uint32_t>(), *qb = c->queue_b.as<uint32_t>();
-    HIPCHK(hipMemsetAsync(c->totals.p, 0, 64, st));
+    HIPCHK(hipMemsetAsync(c->totals.p, 0, 48 * 8, st));
     HIPCHK(hipEventRecord(c->ev[0], st));
     size_t evi = 2;
     const int sgrid = std::min<int64_t>((int64_t)c->n_cu * 8, (cap + MI_BLOCK - 1) / MI_BLOCK);
@@ -321,15 +332,20 @@ MI_API mi_status mi_render_device(mi_ctx *c, const mi_render_params *p, void *d_
         const uint32_t pix0 = (uint32_t)(b * npix_b);
         const uint32_t np = (uint32_t)std::min<int64_t>(npix_b, local - (int64_t)pix0);
         const int64_t nslots = (int64_t)np * spp;
-        HIPCHK(hipMemsetAsync(cnt, 0, 2 * (kMaxLevels + 1) * 4, st));
+        HIPCHK(hipMemsetAsync(cnt, 0, (2 * (kMaxLevels + 1) + 2) * 4, st));
         for (int k = 0; k < levels; k++) {
             uint32_t *qin = (k & 1) ? qb : qa, *qout = (k & 1) ? qa : qb;
             unsigned long long *ws = count_work ? c->totals.as<unsigned long long>() + 2 : nullptr;
             if (per_launch) HIPCHK(hipEventRecord(c->ev[evi++], st));
+            if (k >= 1 && c->tail_threshold > 0 && !count_work)
+                hipLaunchKernelGGL(k_tail, dim3(egrid), dim3(MI_BLOCK), 0, st, c->sc, g, pix0, np, k, p->depth, p->seed, qin, cnt + k,
+                                   (uint32_t)c->tail_threshold, tail_level, c->ray_o.as<float4>(), c->ray_d.as<float4>(), c->thr.as<float4>(),
+                                   c->hist_e.as<float4>(), c->hist_w.as<float4>(), cap, c->path_out.as<float4>(), c->ovf.as<int>(),
+                                   c->totals.as<unsigned long long>() + 7, c->leaf_min, c->shade_min);
 #define MI_EXTEND_ARGS(PRIM)                                                                                                   \
     dim3(egrid), dim3(MI_BLOCK), 0, st, c->sc, (PRIM) ? (const uint32_t *)nullptr : qin, (PRIM) ? (const uint32_t *)nullptr : cnt + k,      \
         (PRIM) ? (uint32_t)nslots : 0u, cur + k, c->ray_o.as<float4>(), c->ray_d.as<float4>(), c->hits.as<float4>(), c->ovf.as<int>(), ws, \
-        c->refill_min, c->static_eighths, c->leaf_min, g, pix0, np, cnt
+        c->refill_min, c->static_eighths, c->leaf_min, g, pix0, np, cnt, tail_level, k
             if (k == 0) {
                 if (count_work) hipLaunchKernelGGL((k_extend<true, true>), MI_EXTEND_ARGS(true));
                 else hipLaunchKernelGGL((k_extend<false, true>), MI_EXTEND_ARGS(true));
@@ -342,7 +358,7 @@ MI_API mi_status mi_render_device(mi_ctx *c, const mi_render_params *p, void *d_
 #define MI_SHADE_ARGS                                                                                                          \
     dim3(sgrid), dim3(MI_BLOCK), 0, st, c->sc, g, pix0, np, k, p->depth - k, p->seed, qin, cnt + k, c->ray_o.as<float4>(),       \
         c->ray_d.as<float4>(), c->thr.as<float4>(), c->hits.as<float4>(), c->hist_e.as<float4>(), c->hist_w.as<float4>(), cap, \
-        c->path_out.as<float4>(), qout, cnt + k + 1, (uint32_t)nslots
+        c->path_out.as<float4>(), qout, cnt + k + 1, (uint32_t)nslots, tail_level
             if (k == 0) hipLaunchKernelGGL(k_shade<true>, MI_SHADE_ARGS);
             else hipLaunchKernelGGL(k_shade<false>, MI_SHADE_ARGS);
 #undef MI_SHADE_ARGS
@@ -353,7 +369,7 @@ MI_API mi_status mi_render_device(mi_ctx *c, const mi_render_params *p, void *d_
         hipLaunchKernelGGL(k_sum_counts, dim3(1), dim3(64), 0, st, cnt, levels, c->totals.as<uint64_t>());
     }
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(c->h_totals, c->totals.p, 64, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(c->h_totals, c->totals.p, 48 * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipEventRecord(c->ev[1], st));
     HIPCHK(hipStreamSynchronize(st));
     if (stats) {
@@ -369,6 +385,11 @@ MI_API mi_status mi_render_device(mi_ctx *c, const mi_render_params *p, void *d_
         if (count_work && getenv("MI_TRACER_DEBUG_LEVELS"))
             fprintf(stderr, "max node steps of one ray %llu, wave iterations total %llu max %llu\n", (unsigned long long)c->h_totals[4],
                     (unsigned long long)c->h_totals[5], (unsigned long long)c->h_totals[6]);
+        if (count_work && getenv("MI_TRACER_DEBUG_LEVELS")) {
+            fprintf(stderr, "node visits by tree depth:");
+            for (int dd = 0; dd < 40; dd++) fprintf(stderr, " %llu", (unsigned long long)c->h_totals[10 + dd]);
+            fprintf(stderr, "\n");
+        }
         if (per_launch) {
             double me = 0, msh = 0;
             for (size_t i = 2; i + 3 <= evi; i += 3) {
@@ -459,7 +480,7 @@ static mi_status probe_chunk(mi_ctx *c, int64_t n, int32_t *prim_id_out, float *
     hipLaunchKernelGGL((k_extend<false, false>), dim3(extend_grid(c)), dim3(MI_BLOCK), 0, st, c->sc, (const uint32_t *)nullptr,
                        (const uint32_t *)nullptr, (uint32_t)n, cur, c->ray_o.as<float4>(), c->ray_d.as<float4>(), c->hits.as<float4>(),
                        c->ovf.as<int>(), (unsigned long long *)nullptr, c->refill_min, c->static_eighths, c->leaf_min, ShardGeom{}, 0u, 1u,
-                       (uint32_t *)nullptr);
+                       (uint32_t *)nullptr, (const uint32_t *)nullptr, 0);
     hipLaunchKernelGGL(k_probe_out, dim3((unsigned)((n + MI_BLOCK - 1) / MI_BLOCK)), dim3(MI_BLOCK), 0, st, c->sc, n, c->ray_o.as<float4>(),
                        c->ray_d.as<float4>(), c->hits.as<float4>(), c->probe_i.as<int32_t>(), c->probe_t.as<float>(),
                        n_out ? c->probe_n.as<float>() : nullptr);

@@ -340,6 +340,18 @@ void Scene::finalize() {
         }
         o[14] = 0; o[15] = 0;
     }
+    // depth of every node (root = 0) in the first spare word: read only by the
+    // instrumented extend kernel (visit histogram per tree level)
+    if (n > 1) {
+        std::vector<std::pair<int32_t, int32_t>> st{{rootRef, 0}};
+        while (!st.empty()) {
+            auto [ref, depth] = st.back();
+            st.pop_back();
+            std::memcpy(nodes_.data() + 16 * (size_t)ref + 14, &depth, 4);
+            for (int c = 0; c < 2; c++)
+                if (builder.nodes[ref].child[c] >= 0) st.push_back({builder.nodes[ref].child[c], depth + 1});
+        }
+    }
     if (n > 0 && rootRef < 0) rootRef = ~slotOfPos[(size_t)~rootRef];
     sah_cost_ = (n > 1 && halfArea(sceneBox) > 0) ? builder.sah / halfArea(sceneBox) : 0;
 
