@@ -753,9 +753,9 @@ k_tail(DevScene sc, ShardGeom g, uint32_t pix0, uint32_t npix, int level0, int d
     const size_t ovf_stride = (size_t)gridDim.x * MI_BLOCK;
     int *my_ovf = ovf + (size_t)blockIdx.x * MI_BLOCK + threadIdx.x;
     const uint32_t n_waves = gridDim.x * (MI_BLOCK / 64);
-    const uint32_t wave_id = blockIdx.x * (MI_BLOCK / 64) + (threadIdx.x >> 6);
+    const uint32_t wave_id = __builtin_amdgcn_readfirstlane(blockIdx.x * (MI_BLOCK / 64) + (threadIdx.x >> 6));
     const uint32_t n_chunks = (n + 63u) >> 6;
-    uint32_t chunk = wave_id;           // static interleaved chunks: wave w takes w, w+W, ...
+    uint32_t chunk = wave_id;           // static interleaved chunks: wave w takes w, w+W, ... (wave-uniform)
     uint32_t rng_next = 0, rng_end = 0; // wave-uniform, in rays
     uint32_t n_extra = 0;               // wave-uniform
 
@@ -767,18 +767,18 @@ k_tail(DevScene sc, ShardGeom g, uint32_t pix0, uint32_t npix, int level0, int d
     L.cur = MI_DONE; L.sp = 0; L.pend0 = L.pend1 = MI_NONE; L.exact = false;
     L.h = Hit{MI_NO_HIT, 0.0f, 0.0f, -1};
     L.o = L.d = L.inv = L.noi = mk3(0, 0, 0);
-    for (;;) {
-        unsigned long long act = __ballot(active);
-        int n_idle = 64 - __popcll(act);
-        bool more = rng_next < rng_end || chunk < n_chunks;
+    unsigned long long act = 0ull;
+    bool more = true; // wave-uniform
+    do {              // single back edge, no `continue` (see k_extend)
+        const int n_idle = 64 - __popcll(act);
         if (more && (n_idle >= 16 || act == 0ull)) {
             if (rng_next >= rng_end) {
                 rng_next = chunk << 6;
                 rng_end = ((chunk + 1) << 6) < n ? ((chunk + 1) << 6) : n;
                 chunk += n_waves;
             }
-            uint32_t rank = (uint32_t)__popcll(~act & ((1ull << lane) - 1ull));
-            uint32_t avail = rng_end - rng_next;
+            const uint32_t rank = (uint32_t)__popcll(~act & ((1ull << lane) - 1ull));
+            const uint32_t avail = rng_end - rng_next;
             if (!active && rank < avail) {
                 slot = queue[rng_next + rank];
                 T = thr[slot];
@@ -787,11 +787,7 @@ k_tail(DevScene sc, ShardGeom g, uint32_t pix0, uint32_t npix, int level0, int d
                 active = true;
             }
             rng_next += (uint32_t)n_idle < avail ? (uint32_t)n_idle : avail;
-            act = __ballot(active);
-        }
-        if (act == 0ull) {
-            if (rng_next < rng_end || chunk < n_chunks) continue;
-            break;
+            more = rng_next < rng_end || chunk < n_chunks;
         }
         const bool want_leaf = active && L.pend0 != MI_NONE;
         const bool want_node = active && L.pend0 == MI_NONE && L.cur != MI_DONE;
@@ -799,13 +795,13 @@ k_tail(DevScene sc, ShardGeom g, uint32_t pix0, uint32_t npix, int level0, int d
         const int nl = __popcll(__ballot(want_leaf)), nn = __popcll(__ballot(want_node)), ns = __popcll(__ballot(want_shade));
         if (ns > 0 && (ns >= shade_min || (nl == 0 && nn == 0))) {
             bool cont = false;
-            f3 no = mk3(0, 0, 0), nd = mk3(0, 0, 0);
-            float4 Tn = T;
             if (want_shade) {
                 uint32_t samp = slot / npix;
                 uint32_t lp = slot - samp * npix;
                 int px, py;
                 local_to_pixel(g, slot_to_local(g, pix0 + lp), px, py);
+                f3 no, nd;
+                float4 Tn;
                 cont = shade_path(sc, seed, path_id(g, px, py, samp), level, depth_total - level, slot, L.o, L.d, T, L.h.t, L.h.slot, L.h.u,
                                   L.h.v, hist_e, hist_w, cap, path_out, no, nd, Tn);
                 if (cont) {
@@ -822,7 +818,8 @@ k_tail(DevScene sc, ShardGeom g, uint32_t pix0, uint32_t npix, int level0, int d
         } else if (want_node) {
             node_phase(sc, L, stack, my_ovf, ovf_stride);
         }
-    }
+        act = __ballot(active);
+    } while (more || act != 0ull);
     if (lane == 0 && n_extra) atomicAdd(extra_rays, (unsigned long long)n_extra);
 }
 

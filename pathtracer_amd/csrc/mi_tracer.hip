@@ -76,6 +76,10 @@ struct mi_ctx {
 };
 
 static const int kMaxLevels = 64; // counters reserved per batch (depth + 2 must fit)
+// totals[]: 0 rays, 1 paths, 2.. = work_stats of the instrumented extend kernel
+// (+0 node visits, +1 primitive tests, +2 max steps of a ray, +3/+4 wave iterations
+// total/max, +5 rays k_tail traced beyond its first level, +8..+47 visits per tree depth)
+static const int kTotals = 64;
 
 static int extend_grid(const mi_ctx *c) { return c->n_cu * c->extend_wg_per_cu; }
 
@@ -110,7 +114,7 @@ MI_API mi_status mi_ctx_create(int device_id, mi_ctx **out) {
     c->static_eighths = (uint32_t)env_int("MI_TRACER_STATIC_EIGHTHS", 0, 8, (int)c->static_eighths);
     hipError_t es = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (es != hipSuccess) { delete c; return fail(MI_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(es)); }
-    es = hipHostMalloc((void **)&c->h_totals, 48 * sizeof(uint64_t), hipHostMallocDefault);
+    es = hipHostMalloc((void **)&c->h_totals, kTotals * sizeof(uint64_t), hipHostMallocDefault);
     if (es != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return fail(MI_ERR_HIP, "hipHostMalloc failed: %s", hipGetErrorString(es)); }
     *out = c;
     return MI_OK;
@@ -313,7 +317,7 @@ MI_API mi_status mi_render_device(mi_ctx *c, const mi_render_params *p, void *d_
     HIPCHK(c->counters.ensure((2 * (kMaxLevels + 1) + 2) * 4));
     const int egrid = extend_grid(c);
     HIPCHK(c->ovf.ensure((size_t)(MI_MAX_STACK - MI_LDS_STACK) * egrid * MI_BLOCK * 4));
-    HIPCHK(c->totals.ensure(48 * 8));
+    HIPCHK(c->totals.ensure(kTotals * 8));
     const int64_t n_batches = local > 0 ? (local + npix_b - 1) / npix_b : 0;
     const size_t n_ev = 2 + (size_t)n_batches * levels * 3;
     const bool per_launch = n_ev <= 4096; // per-launch timing only while the event count stays modest
@@ -324,7 +328,7 @@ MI_API mi_status mi_render_device(mi_ctx *c, const mi_render_params *p, void *d_
     uint32_t *cur = cnt + (kMaxLevels + 1);              // cur[k] = work cursor of extend at level k
     uint32_t *tail_level = cnt + 2 * (kMaxLevels + 1);    // 0, or the level at which k_tail took over
     uint32_t *qa = c->queue_a.as<uint32_t>(), *qb = c->queue_b.as<uint32_t>();
-    HIPCHK(hipMemsetAsync(c->totals.p, 0, 48 * 8, st));
+    HIPCHK(hipMemsetAsync(c->totals.p, 0, kTotals * 8, st));
     HIPCHK(hipEventRecord(c->ev[0], st));
     size_t evi = 2;
     const int sgrid = std::min<int64_t>((int64_t)c->n_cu * 8, (cap + MI_BLOCK - 1) / MI_BLOCK);
@@ -369,7 +373,7 @@ MI_API mi_status mi_render_device(mi_ctx *c, const mi_render_params *p, void *d_
         hipLaunchKernelGGL(k_sum_counts, dim3(1), dim3(64), 0, st, cnt, levels, c->totals.as<uint64_t>());
     }
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(c->h_totals, c->totals.p, 48 * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(c->h_totals, c->totals.p, kTotals * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipEventRecord(c->ev[1], st));
     HIPCHK(hipStreamSynchronize(st));
     if (stats) {
