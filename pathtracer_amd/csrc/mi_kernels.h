@@ -772,21 +772,23 @@ k_tail(DevScene sc, ShardGeom g, uint32_t pix0, uint32_t npix, int level0, int d
     do {              // single back edge, no `continue` (see k_extend)
         const int n_idle = 64 - __popcll(act);
         if (more && (n_idle >= 16 || act == 0ull)) {
-            if (rng_next >= rng_end) {
+            if (rng_next >= rng_end && chunk < n_chunks) { // chunk < n_chunks  =>  chunk*64 < n
                 rng_next = chunk << 6;
                 rng_end = ((chunk + 1) << 6) < n ? ((chunk + 1) << 6) : n;
                 chunk += n_waves;
             }
-            const uint32_t rank = (uint32_t)__popcll(~act & ((1ull << lane) - 1ull));
-            const uint32_t avail = rng_end - rng_next;
-            if (!active && rank < avail) {
-                slot = queue[rng_next + rank];
-                T = thr[slot];
-                level = level0;
-                lane_start(sc, L, xyz(ray_o[slot]), xyz(ray_d[slot]));
-                active = true;
+            if (rng_next < rng_end) {
+                const uint32_t rank = (uint32_t)__popcll(~act & ((1ull << lane) - 1ull));
+                const uint32_t avail = rng_end - rng_next;
+                if (!active && rank < avail) {
+                    slot = queue[rng_next + rank];
+                    T = thr[slot];
+                    level = level0;
+                    lane_start(sc, L, xyz(ray_o[slot]), xyz(ray_d[slot]));
+                    active = true;
+                }
+                rng_next += (uint32_t)n_idle < avail ? (uint32_t)n_idle : avail;
             }
-            rng_next += (uint32_t)n_idle < avail ? (uint32_t)n_idle : avail;
             more = rng_next < rng_end || chunk < n_chunks;
         }
         const bool want_leaf = active && L.pend0 != MI_NONE;
