@@ -190,3 +190,13 @@ def test_raycheck_rms_subtracts_without_uint8_wraparound():
     assert O.raycheck_rms(a, b) == pytest.approx(3.0) and O.raycheck_rms(b, a) == pytest.approx(3.0)
     b[0, 0, 0] = 255
     assert O.raycheck_rms(a, b) == pytest.approx(math.sqrt((47 * 9 + 255 ** 2) / 48))
+
+
+def test_raycheck_module_metric_equals_oracle_metric():
+    from pathtracer_amd import raycheck
+    rng = np.random.default_rng(2)
+    a = rng.integers(0, 256, (9, 7, 3), dtype=np.uint8)
+    b = rng.integers(0, 256, (9, 7, 3), dtype=np.uint8)
+    assert raycheck.rms(a, b) == pytest.approx(O.raycheck_rms(a, b), rel=1e-12)
+    with pytest.raises(ValueError):
+        raycheck.rms(a, b[:-1])
