@@ -92,11 +92,13 @@ def main():
     fence()
     t0 = time.perf_counter()
     rays = 0
+    rays_ext = 0
     ms_extend = 0.0
     n_ext = 0
     for _ in range(args.steps):
         st, img = step()
         rays += st.rays_cast
+        rays_ext += st.rays_extend
         ms_extend += st.ms_extend
         n_ext += st.extend_launches
     fence()
@@ -121,7 +123,7 @@ def main():
         nodes_per_ray, leaves_per_ray = stc.node_visits / r, stc.prim_tests / r
         bytes_per_ray = 64.0 * nodes_per_ray + 64.0 * leaves_per_ray + 128.0
         flops_per_ray = 54.0 * nodes_per_ray + 37.0 * leaves_per_ray + 160.0
-        rays_rank0_per_step = rays / args.steps
+        rays_rank0_per_step = rays_ext / args.steps   # rays traced by k_extend launches (k_tail's excluded)
         launches_per_step = max(1, n_ext // args.steps)
         avg_launch_ms = ms_extend / max(1, n_ext)
         bytes_per_launch = bytes_per_ray * rays_rank0_per_step / launches_per_step
@@ -148,7 +150,12 @@ def main():
                          "bytes_per_ray": bytes_per_ray, "nodes_per_ray": nodes_per_ray, "prim_tests_per_ray": leaves_per_ray,
                          "avg_launch_ms": avg_launch_ms, "launches_per_step": launches_per_step,
                          "valu_tflops": valu_tflops, "valu_frac": valu_tflops / VALU_PEAK_TFLOPS,
-                         "extend_share_of_step": (ms_extend / args.steps) / (dt / args.steps * 1e3)},
+                         "extend_share_of_step": (ms_extend / args.steps) / (dt / args.steps * 1e3),
+                         "rays_in_kernel_per_step": rays_rank0_per_step,
+                         "note": "achieved = algorithmic bytes (64 B per node visit and per primitive test + 128 B queue traffic "
+                                 "per ray, counted on the GPU's own traversal) / k_extend time; the ~10 MB scene is L2/MALL "
+                                 "resident, so most of these bytes never reach HBM (see traffic) and frac can exceed 1: the "
+                                 "kernel is VALU-issue/latency bound, not HBM bound (DESIGN.md section 3)"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, w, h, samples, depth, args.cpu_seconds)

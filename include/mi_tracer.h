@@ -116,11 +116,14 @@ typedef struct mi_stats {
     double ms_total;         /* first launch -> outputs complete (HIP events)       */
     double ms_extend;        /* sum over launches of the BVH extend kernel          */
     double ms_shade;         /* sum over launches of the shade+compact kernel       */
-    double ms_other;         /* generate + resolve                                  */
+    double ms_other;         /* everything else (resolve, memsets, gaps)             */
     uint32_t extend_launches;
     uint32_t batches;
     uint64_t node_visits;    /* only with count_work: interior nodes fetched          */
     uint64_t prim_tests;     /* only with count_work: primitive records tested        */
+    uint64_t rays_extend;    /* rays traced by the per-level extend kernel (the rest,
+                                rays_cast - rays_extend, by the tail kernel)           */
+    double ms_tail;          /* sum over launches of the tail kernel                   */
 } mi_stats;
 
 /* Create a context on HIP device `device_id`.  One context = one GPU; multi-GPU

@@ -56,7 +56,7 @@ class Stats(C.Structure):
     _fields_ = [
         ("rays_cast", C.c_uint64), ("paths", C.c_uint64), ("ms_total", C.c_double), ("ms_extend", C.c_double),
         ("ms_shade", C.c_double), ("ms_other", C.c_double), ("extend_launches", C.c_uint32), ("batches", C.c_uint32),
-        ("node_visits", C.c_uint64), ("prim_tests", C.c_uint64),
+        ("node_visits", C.c_uint64), ("prim_tests", C.c_uint64), ("rays_extend", C.c_uint64), ("ms_tail", C.c_double),
     ]
 
 

@@ -520,8 +520,10 @@ k_extend(DevScene sc, const uint32_t *queue, const uint32_t *count_ptr, uint32_t
             if (COUNT) {
                 n_nodes++;
                 ray_steps++;
+#ifdef MI_DEPTH_HISTOGRAM // visits per tree level (slow: contended atomics); used once to size an LDS treelet
                 int depth = __float_as_int(sc.nodes[4 * (size_t)L.cur + 3].z);
                 atomicAdd(&work_stats[8 + (depth < 40 ? depth : 39)], 1ull);
+#endif
             }
             node_phase(sc, L, stack, my_ovf, ovf_stride);
         }

@@ -83,7 +83,7 @@ static const int kTotals = 64;
 
 static int extend_grid(const mi_ctx *c) { return c->n_cu * c->extend_wg_per_cu; }
 
-MI_API int mi_abi_version(void) { return 2; }
+MI_API int mi_abi_version(void) { return 3; }
 MI_API const char *mi_last_error(void) { return g_err.c_str(); }
 
 MI_API mi_status mi_ctx_create(int device_id, mi_ctx **out) {
@@ -148,6 +148,8 @@ static mi_status validate_scene(const mi_scene_soa *s) {
         if (s->tri_mat[i] >= s->n_mat) return fail(MI_ERR_INVALID, "scene: triangle material id out of range");
     for (uint32_t i = 0; i < s->n_sph; i++)
         if (s->sph_mat[i] >= s->n_mat) return fail(MI_ERR_INVALID, "scene: sphere material id out of range");
+    // node and triangle records are addressed with 32-bit byte offsets (64 B each)
+    if (s->n_nodes >= (1u << 26) || s->n_tri >= (1u << 26)) return fail(MI_ERR_INVALID, "scene: more than 2^26 nodes or triangles");
     if (n_prim == 1) {
         if (s->root_ref != ~0) return fail(MI_ERR_INVALID, "scene: one primitive needs root_ref == ~0");
         return MI_OK;
@@ -274,10 +276,15 @@ static mi_status get_events(mi_ctx *c, size_t n) {
     return MI_OK;
 }
 
-__global__ void k_sum_counts(const uint32_t *counts, int n, uint64_t *totals) {
+__global__ void k_sum_counts(const uint32_t *counts, int n, uint64_t *totals, const uint32_t *tail_level) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
-        uint64_t s = 0;
-        for (int i = 0; i < n; i++) s += counts[i];
+        uint64_t s = 0, ext = 0;
+        const uint32_t tl = *tail_level; // 0, or the level k_tail took over at
+        for (int i = 0; i < n; i++) {
+            s += counts[i];
+            if (tl == 0 || (uint32_t)i < tl) ext += counts[i];
+        }
+        totals[8] += ext; // rays traced by k_extend launches
         totals[0] += s + totals[7]; // rays cast = sum of extend queue lengths + rays k_tail traced beyond its first level
         totals[7] = 0;
         totals[1] += counts[0];     // paths started
@@ -319,7 +326,7 @@ MI_API mi_status mi_render_device(mi_ctx *c, const mi_render_params *p, void *d_
     HIPCHK(c->ovf.ensure((size_t)(MI_MAX_STACK - MI_LDS_STACK) * egrid * MI_BLOCK * 4));
     HIPCHK(c->totals.ensure(kTotals * 8));
     const int64_t n_batches = local > 0 ? (local + npix_b - 1) / npix_b : 0;
-    const size_t n_ev = 2 + (size_t)n_batches * levels * 3;
+    const size_t n_ev = 2 + (size_t)n_batches * levels * 4;
     const bool per_launch = n_ev <= 4096; // per-launch timing only while the event count stays modest
     mi_status es = get_events(c, per_launch ? n_ev : 2);
     if (es != MI_OK) return es;
@@ -340,12 +347,13 @@ MI_API mi_status mi_render_device(mi_ctx *c, const mi_render_params *p, void *d_
         for (int k = 0; k < levels; k++) {
             uint32_t *qin = (k & 1) ? qb : qa, *qout = (k & 1) ? qa : qb;
             unsigned long long *ws = count_work ? c->totals.as<unsigned long long>() + 2 : nullptr;
-            if (per_launch) HIPCHK(hipEventRecord(c->ev[evi++], st));
+            if (per_launch) HIPCHK(hipEventRecord(c->ev[evi++], st)); // 4 events per level: tail | extend | shade
             if (k >= 1 && c->tail_threshold > 0 && !count_work)
                 hipLaunchKernelGGL(k_tail, dim3(egrid), dim3(MI_BLOCK), 0, st, c->sc, g, pix0, np, k, p->depth, p->seed, qin, cnt + k,
                                    (uint32_t)c->tail_threshold, tail_level, c->ray_o.as<float4>(), c->ray_d.as<float4>(), c->thr.as<float4>(),
                                    c->hist_e.as<float4>(), c->hist_w.as<float4>(), cap, c->path_out.as<float4>(), c->ovf.as<int>(),
                                    c->totals.as<unsigned long long>() + 7, c->leaf_min, c->shade_min);
+            if (per_launch) HIPCHK(hipEventRecord(c->ev[evi++], st));
 #define MI_EXTEND_ARGS(PRIM)                                                                                                   \
     dim3(egrid), dim3(MI_BLOCK), 0, st, c->sc, (PRIM) ? (const uint32_t *)nullptr : qin, (PRIM) ? (const uint32_t *)nullptr : cnt + k,      \
         (PRIM) ? (uint32_t)nslots : 0u, cur + k, c->ray_o.as<float4>(), c->ray_d.as<float4>(), c->hits.as<float4>(), c->ovf.as<int>(), ws, \
@@ -370,7 +378,7 @@ MI_API mi_status mi_render_device(mi_ctx *c, const mi_render_params *p, void *d_
         }
         hipLaunchKernelGGL(k_resolve, dim3((np + MI_BLOCK - 1) / MI_BLOCK), dim3(MI_BLOCK), 0, st, g, pix0, np, c->path_out.as<float4>(),
                            (float4 *)d_rgba_mean, (uchar4 *)d_rgba8);
-        hipLaunchKernelGGL(k_sum_counts, dim3(1), dim3(64), 0, st, cnt, levels, c->totals.as<uint64_t>());
+        hipLaunchKernelGGL(k_sum_counts, dim3(1), dim3(64), 0, st, cnt, levels, c->totals.as<uint64_t>(), tail_level);
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(c->h_totals, c->totals.p, kTotals * 8, hipMemcpyDeviceToHost, st));
@@ -394,13 +402,15 @@ MI_API mi_status mi_render_device(mi_ctx *c, const mi_render_params *p, void *d_
             for (int dd = 0; dd < 40; dd++) fprintf(stderr, " %llu", (unsigned long long)c->h_totals[10 + dd]);
             fprintf(stderr, "\n");
         }
+        stats->rays_extend = c->h_totals[8];
         if (per_launch) {
-            double me = 0, msh = 0;
-            for (size_t i = 2; i + 3 <= evi; i += 3) {
-                float a = 0, b2 = 0;
-                HIPCHK(hipEventElapsedTime(&a, c->ev[i], c->ev[i + 1]));
-                HIPCHK(hipEventElapsedTime(&b2, c->ev[i + 1], c->ev[i + 2]));
-                me += a; msh += b2;
+            double me = 0, msh = 0, mt = 0;
+            for (size_t i = 2; i + 4 <= evi; i += 4) {
+                float t0 = 0, a = 0, b2 = 0;
+                HIPCHK(hipEventElapsedTime(&t0, c->ev[i], c->ev[i + 1]));
+                HIPCHK(hipEventElapsedTime(&a, c->ev[i + 1], c->ev[i + 2]));
+                HIPCHK(hipEventElapsedTime(&b2, c->ev[i + 2], c->ev[i + 3]));
+                mt += t0; me += a; msh += b2;
                 stats->extend_launches++;
             }
             if (getenv("MI_TRACER_DEBUG_LEVELS")) { // per-launch timings and queue lengths, for tuning only
@@ -408,16 +418,19 @@ MI_API mi_status mi_render_device(mi_ctx *c, const mi_render_params *p, void *d_
                 (void)hipMemcpy(hc.data(), cnt, hc.size() * 4, hipMemcpyDeviceToHost); // counts of the LAST batch
                 size_t j = 2;
                 for (int64_t b = 0; b < n_batches; b++)
-                    for (int k = 0; k < levels; k++, j += 3) {
-                        float a = 0, b2 = 0;
-                        (void)hipEventElapsedTime(&a, c->ev[j], c->ev[j + 1]);
-                        (void)hipEventElapsedTime(&b2, c->ev[j + 1], c->ev[j + 2]);
-                        fprintf(stderr, "batch %lld level %d rays %u extend %.3f ms shade %.3f ms\n", (long long)b, k, b == n_batches - 1 ? hc[k] : 0u, a, b2);
+                    for (int k = 0; k < levels; k++, j += 4) {
+                        float t0 = 0, a = 0, b2 = 0;
+                        (void)hipEventElapsedTime(&t0, c->ev[j], c->ev[j + 1]);
+                        (void)hipEventElapsedTime(&a, c->ev[j + 1], c->ev[j + 2]);
+                        (void)hipEventElapsedTime(&b2, c->ev[j + 2], c->ev[j + 3]);
+                        fprintf(stderr, "batch %lld level %d rays %u tail %.3f ms extend %.3f ms shade %.3f ms\n", (long long)b, k,
+                                b == n_batches - 1 ? hc[k] : 0u, t0, a, b2);
                     }
             }
+            stats->ms_tail = mt;
             stats->ms_extend = me;
             stats->ms_shade = msh;
-            stats->ms_other = std::max(0.0, stats->ms_total - me - msh);
+            stats->ms_other = std::max(0.0, stats->ms_total - me - msh - mt);
         }
     }
     return MI_OK;
