@@ -136,10 +136,11 @@ __device__ __forceinline__ uint32_t slot_to_local(const ShardGeom &g, uint32_t l
     return j * tpix + y * (uint32_t)g.tile_w + x;
 }
 
-// Queue append (ray-queue compaction): wave ballot + popcount prefix inside each wave,
-// the four wave totals combined through LDS, ONE global atomic per workgroup.  Must be
-// called by every thread of the workgroup (it contains barriers).
-__device__ __forceinline__ void queue_append(bool alive, uint32_t slot, uint32_t *queue, uint32_t *count) {
+// Ray-queue compaction: wave ballot + popcount prefix inside each wave, the four wave
+// totals combined through LDS, ONE global atomic per workgroup.  Returns the position
+// reserved for this thread's ray in the next level's ray stream (meaningful only when
+// `alive`).  Must be called by every thread of the workgroup (it contains barriers).
+__device__ __forceinline__ uint32_t queue_reserve(bool alive, uint32_t *count) {
     __shared__ uint32_t wave_cnt[MI_BLOCK / 64];
     __shared__ uint32_t block_base;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -154,8 +155,67 @@ __device__ __forceinline__ void queue_append(bool alive, uint32_t slot, uint32_t
     __syncthreads();
     uint32_t prefix = block_base;
     for (int w = 0; w < wave; w++) prefix += wave_cnt[w];
-    if (alive) queue[prefix + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = slot;
+    const uint32_t pos = prefix + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
     __syncthreads(); // wave_cnt / block_base are reused by the next call
+    return pos;
+}
+
+// The rays of one level form a dense STREAM of records at positions [0, count): the
+// payload travels with the queue instead of being looked up through a slot index, so
+// every kernel reads and writes it with unit stride (at deeper levels the survivors are
+// scattered over the slot range: one 16-B read per 128-B line otherwise).
+//   o[i] = (origin, path slot as int bits)   d[i] = (direction, 0)   thr[i] = throughput
+// Only the per-path history and the final path value stay indexed by slot.
+//
+// A stream is split into MI_SUB sub-streams, each with its own counter word:
+// sub-stream k holds positions [k*segcap, k*segcap + cnt[k]).  A single counter word
+// sustains only ~88 returning atomics/us on MI355X (one per 256 appended rays = 130k
+// atomics for the 33M primary rays of the 1080p workload: the shade kernel was bound by
+// them); the rate scales linearly with the number of words.  Workgroup b appends to
+// sub-stream b % MI_SUB.  Consumers walk a VIRTUAL sequence of 64-ray chunks, the chunks
+// of sub-stream 0 first, then 1, ...; stream_chunk() maps a virtual chunk to its rays.
+#ifndef MI_SUB
+#define MI_SUB 16
+#endif
+#define MI_CNT_STRIDE 32 // words between counters: every counter word has a 128-B line of its own
+struct RayStream {
+    float4 *o, *d, *thr;
+    uint32_t segcap; // positions reserved per sub-stream
+};
+// Number of virtual chunks of a stream.  cnt == nullptr: one identity sub-stream of
+// `fixed` rays (level 0, probes).  All arguments wave-uniform (scalar code).
+__device__ __forceinline__ uint32_t stream_chunks(const uint32_t *cnt, uint32_t fixed) {
+    if (!cnt) return (fixed + 63u) >> 6;
+    uint32_t n = 0;
+#pragma unroll
+    for (int k = 0; k < MI_SUB; k++) n += (cnt[k * MI_CNT_STRIDE] + 63u) >> 6;
+    return n;
+}
+__device__ __forceinline__ uint32_t stream_total(const uint32_t *cnt) {
+    uint32_t n = 0;
+#pragma unroll
+    for (int k = 0; k < MI_SUB; k++) n += cnt[k * MI_CNT_STRIDE];
+    return n;
+}
+// Virtual chunk v (< stream_chunks) -> ray positions [first, end), end - first <= 64.
+__device__ __forceinline__ void stream_chunk(const uint32_t *cnt, uint32_t fixed, uint32_t segcap, uint32_t v, uint32_t &first, uint32_t &end) {
+    if (!cnt) {
+        first = v << 6;
+        end = first + 64u < fixed ? first + 64u : fixed;
+        return;
+    }
+    uint32_t pre = 0;
+    first = end = 0;
+#pragma unroll
+    for (int k = 0; k < MI_SUB; k++) {
+        const uint32_t c = cnt[k * MI_CNT_STRIDE], nc = (c + 63u) >> 6;
+        if (v >= pre && v < pre + nc) {
+            const uint32_t off = (v - pre) << 6;
+            first = (uint32_t)k * segcap + off;
+            end = (uint32_t)k * segcap + (off + 64u < c ? off + 64u : c);
+        }
+        pre += nc;
+    }
 }
 
 // ------------------------------------------------------------------ generate
@@ -341,7 +401,8 @@ __device__ __forceinline__ void lane_start(const DevScene &sc, Lane &L, f3 o, f3
 }
 // Node phase of one lane: fetch node L.cur (64 B), slab-test both child boxes, queue
 // leaf children as pending, descend near-first / pop (bvh.cu:178-207 restructured).
-__device__ __forceinline__ void node_phase(const DevScene &sc, Lane &L, int *stack, int *my_ovf, size_t ovf_stride) {
+typedef __attribute__((address_space(3))) int lds_int; // LDS-qualified, so stack accesses can only be ds_read/ds_write
+__device__ __forceinline__ void node_phase(const DevScene &sc, Lane &L, lds_int *stack, int *my_ovf, size_t ovf_stride) {
     const char *nd = (const char *)sc.nodes + ((uint32_t)L.cur << 6);
     float4 n0 = *(const float4 *)(nd), n1 = *(const float4 *)(nd + 16), n2 = *(const float4 *)(nd + 32);
     int2 refs = *(const int2 *)(nd + 48);
@@ -371,8 +432,14 @@ __device__ __forceinline__ void node_phase(const DevScene &sc, Lane &L, int *sta
     } else if (L.sp == 0) {
         L.cur = MI_DONE;
     } else {
+        // The LDS read is unconditional (clamped index) and the rare overflow entry
+        // overrides it: a `?:` over the two address spaces compiles to one flat_load,
+        // which is slower than ds_read and makes every later wait cover both counters
+        // (hence also the LDS-qualified pointer type).
         L.sp--;
-        L.cur = L.sp < MI_LDS_STACK ? stack[L.sp * MI_BLOCK] : my_ovf[(size_t)(L.sp - MI_LDS_STACK) * ovf_stride];
+        int top = stack[(L.sp < MI_LDS_STACK ? L.sp : MI_LDS_STACK - 1) * MI_BLOCK];
+        if (L.sp >= MI_LDS_STACK) top = my_ovf[(size_t)(L.sp - MI_LDS_STACK) * ovf_stride];
+        L.cur = top;
     }
 }
 __device__ __forceinline__ void leaf_phase(const DevScene &sc, Lane &L) { // one pending primitive
@@ -398,43 +465,37 @@ __device__ __forceinline__ void leaf_phase(const DevScene &sc, Lane &L) { // one
 //
 // Work distribution and refill: see the comments in the kernel body.  Every wave leaves
 // through the same exit (work exhausted and no lane active).
-// queue == nullptr means the identity queue (slot = index).
+// Ray i of the level's stream is (ray_o[i], ray_d[i]); its hit goes to hits[i].
 // COUNT = true is the instrumented build used once per bench run (outside the timed
 // region) to measure node visits and primitive tests per ray: work_stats[0] += node
 // visits, [1] += primitive tests.
-// PRIMARY = true is level 0: the queue is the identity over the batch's slots, rays
+// PRIMARY = true is level 0: the stream is the identity over the batch's slots, rays
 // come from primary_ray(), and the number of slots that are real pixels is added to
 // *primary_count (it is the level-0 ray count).
 template <bool COUNT, bool PRIMARY>
 __global__ void __launch_bounds__(MI_BLOCK)
-k_extend(DevScene sc, const uint32_t *queue, const uint32_t *count_ptr, uint32_t fixed_count, uint32_t *cursor,
+k_extend(DevScene sc, const uint32_t *count_ptr, uint32_t fixed_count, uint32_t segcap,
          const float4 *ray_o, const float4 *ray_d, float4 *hits, int *ovf, unsigned long long *work_stats, int refill_min,
-         uint32_t static_eighths, int leaf_min, ShardGeom g, uint32_t pix0, uint32_t npix, uint32_t *primary_count,
+         int leaf_min, ShardGeom g, uint32_t pix0, uint32_t npix, uint32_t *primary_count,
          const uint32_t *tail_level, int level) {
     __shared__ int lds_stack[MI_LDS_STACK * MI_BLOCK];
     if (!PRIMARY && tail_level && tail_took_over(tail_level, level)) return;
-    const uint32_t n = count_ptr ? *count_ptr : fixed_count;
     const int lane = threadIdx.x & 63;
-    int *stack = lds_stack + threadIdx.x;
+    lds_int *stack = (lds_int *)lds_stack + threadIdx.x;
     const size_t ovf_stride = (size_t)gridDim.x * MI_BLOCK;
     int *my_ovf = ovf + (size_t)blockIdx.x * MI_BLOCK + threadIdx.x;
-    // Work distribution in 64-ray chunks.  The first static_eighths/8 of the chunks are
-    // dealt statically, interleaved over the waves (wave w takes chunks w, w+W, w+2W, ...:
-    // no atomics, and every wave sees the same mix of image regions); the rest is pulled
-    // dynamically, 4 chunks per returning atomic (a single word sustains only ~90
-    // returning atomics/us), to even out the tail.
+    // Work distribution in 64-ray chunks, dealt statically and interleaved over the waves
+    // (wave w takes virtual chunks w, w+W, w+2W, ...): no atomics (a work cursor on one
+    // word cost 6 of 7 ms at level 0), and every wave sees the same mix of image regions.
     // Wave-uniform bookkeeping is kept in SGPRs (readfirstlane) and the loop has a single
     // back edge and no `continue`: with a more tangled control flow the compiler copies
     // the whole per-lane state (≈45 v_mov) on every iteration.
     const uint32_t n_waves = gridDim.x * (MI_BLOCK / 64);
     const uint32_t wave_id = __builtin_amdgcn_readfirstlane(blockIdx.x * (MI_BLOCK / 64) + (threadIdx.x >> 6));
-    const uint32_t n_chunks = (n + 63u) >> 6;
-    uint32_t static_per_wave = (uint32_t)(((uint64_t)n_chunks * static_eighths) / (8u * n_waves));
-    if (static_per_wave == 0) static_per_wave = 1;
-    const uint32_t dyn_first = static_per_wave * n_waves; // first dynamically dealt chunk
-    uint32_t static_k = 0;                                // wave-uniform
-    uint32_t rng_next = 0, rng_end = 0;                   // wave-uniform, in rays
-    uint32_t more = 1;                                    // wave-uniform: chunks may remain
+    const uint32_t n_chunks = stream_chunks(count_ptr, fixed_count);
+    uint32_t chunk = wave_id;           // next virtual chunk of this wave (wave-uniform)
+    uint32_t rng_next = 0, rng_end = 0; // wave-uniform, ray positions
+    bool more = chunk < n_chunks;       // wave-uniform: rays may remain for this wave
     uint32_t n_nodes = 0, n_leaves = 0, ray_steps = 0, max_ray_steps = 0, wave_iters = 0;
     uint32_t n_primary = 0; // wave-uniform
 
@@ -451,35 +512,11 @@ k_extend(DevScene sc, const uint32_t *queue, const uint32_t *count_ptr, uint32_t
         // leave lanes idle for the rest of a 64-ray packet.
         const int n_idle = 64 - __popcll(act);
         if (more && (n_idle >= refill_min || act == 0ull)) {
-            if (rng_next >= rng_end) {
-                uint32_t c0 = n_chunks, c1 = n_chunks; // next chunk range [c0, c1)
-                if (static_k < static_per_wave) {
-                    c0 = wave_id + static_k * n_waves;
-                    c1 = c0 + 1;
-                    static_k++;
-                } else if (dyn_first < n_chunks) {
-                    // a relaxed load first: waves that arrive after the queue is drained do
-                    // not add to the traffic on the cursor word
-                    uint32_t seen = 0;
-                    if (lane == 0) seen = __hip_atomic_load(cursor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    seen = __builtin_amdgcn_readfirstlane(seen);
-                    if (dyn_first + seen < n_chunks) {
-                        uint32_t got = 0;
-                        if (lane == 0) got = atomicAdd(cursor, 4u);
-                        got = __builtin_amdgcn_readfirstlane(got);
-                        c0 = dyn_first + got;
-                        c1 = c0 + 4;
-                    }
-                }
-                c0 = __builtin_amdgcn_readfirstlane(c0);
-                c1 = __builtin_amdgcn_readfirstlane(c1);
-                if (c0 >= n_chunks) {
-                    if (static_k >= static_per_wave) more = 0;
-                    rng_next = rng_end = 0;
-                } else {
-                    rng_next = c0 << 6;
-                    rng_end = (c1 << 6) < n ? (c1 << 6) : n;
-                }
+            if (rng_next >= rng_end && chunk < n_chunks) {
+                stream_chunk(count_ptr, fixed_count, segcap, chunk, rng_next, rng_end);
+                rng_next = __builtin_amdgcn_readfirstlane(rng_next);
+                rng_end = __builtin_amdgcn_readfirstlane(rng_end);
+                chunk += n_waves;
             }
             if (rng_next < rng_end) {
                 const uint32_t rank = (uint32_t)__popcll(~act & ((1ull << lane) - 1ull));
@@ -496,9 +533,9 @@ k_extend(DevScene sc, const uint32_t *queue, const uint32_t *count_ptr, uint32_t
                     }
                     n_primary += (uint32_t)__popcll(__ballot(take));
                 } else if (take) {
-                    slot = queue ? queue[idx] : idx;
-                    o = xyz(ray_o[slot]);
-                    d = xyz(ray_d[slot]);
+                    slot = idx;
+                    o = xyz(ray_o[idx]);
+                    d = xyz(ray_d[idx]);
                 }
                 if (take) {
                     lane_start(sc, L, o, d);
@@ -506,6 +543,7 @@ k_extend(DevScene sc, const uint32_t *queue, const uint32_t *count_ptr, uint32_t
                 }
                 rng_next += (uint32_t)n_idle < avail ? (uint32_t)n_idle : avail;
             }
+            more = rng_next < rng_end || chunk < n_chunks;
         }
         if (COUNT) wave_iters++;
         const bool want_leaf = active && L.pend0 != MI_NONE;
@@ -565,12 +603,19 @@ __device__ __forceinline__ void hit_surface(const DevScene &sc, int slot, float 
         const uint32_t *mid = sc.tri_mat + 3 * (size_t)slot;
         if (sc.tri_has_vmat[slot]) { // trimesh.cu:110-116 with material.h:91-100,137-146
             float w = 1 - u - v;     // trimesh.cu:102
-            DMat a = load_mat(sc, mid[0]), b = load_mat(sc, mid[1]), c = load_mat(sc, mid[2]);
-            m.ke = add4(add4(mul4(a.ke, w), mul4(b.ke, u)), mul4(c.ke, v));
-            m.kd = add4(add4(mul4(a.kd, w), mul4(b.kd, u)), mul4(c.kd, v));
-            m.kr = add4(add4(mul4(a.kr, w), mul4(b.kr, u)), mul4(c.kr, v));
-            m.kt = add4(add4(mul4(a.kt, w), mul4(b.kt, u)), mul4(c.kt, v));
-            m.index = a.index * w + b.index * u + c.index * v;
+            // (a*w + b*u) + c*v, accumulated one vertex material at a time (same
+            // association, a third of the registers of loading all three first)
+            const float wt[3] = {w, u, v};
+            DMat a = load_mat(sc, mid[0]);
+            m.ke = mul4(a.ke, w); m.kd = mul4(a.kd, w); m.kr = mul4(a.kr, w); m.kt = mul4(a.kt, w);
+            m.index = a.index * w;
+#pragma unroll 1
+            for (int k = 1; k < 3; k++) {
+                DMat b = load_mat(sc, mid[k]);
+                m.ke = add4(m.ke, mul4(b.ke, wt[k])); m.kd = add4(m.kd, mul4(b.kd, wt[k]));
+                m.kr = add4(m.kr, mul4(b.kr, wt[k])); m.kt = add4(m.kt, mul4(b.kt, wt[k]));
+                m.index = m.index + b.index * wt[k];
+            }
         } else {
             m = load_mat(sc, mid[0]);
         }
@@ -592,9 +637,11 @@ __device__ __forceinline__ f3 hemisphere(f3 N, float u1, float u2) {
 // The reference evaluates radiance by recursion: value_k = ke_k*32 + w_k (.) value_{k+1}
 // (CpuTracer.cu:152,166,174,185).  To round exactly like it, every level stores
 // (e_k, w_k) and the terminating thread folds them from the deepest level back.
-__device__ __forceinline__ float4 fold_history(const float4 *hist_e, const float4 *hist_w, size_t cap, uint32_t slot, int levels, float4 val) {
+// hist[(level*cap + slot)*2 + {0,1}] = (e, w): one 32-B record per path and level.
+__device__ __forceinline__ float4 fold_history(const float4 *hist, size_t cap, uint32_t slot, int levels, float4 val) {
     for (int j = levels - 1; j >= 0; j--) {
-        float4 e = hist_e[(size_t)j * cap + slot], w = hist_w[(size_t)j * cap + slot];
+        const float4 *rec = hist + ((size_t)j * cap + slot) * 2;
+        float4 e = rec[0], w = rec[1];
         val = add4(e, mul4(w, val));
     }
     return val;
@@ -615,10 +662,10 @@ __device__ __forceinline__ uint64_t path_id(const ShardGeom &g, int px, int py, 
 // or (e, w) of this level are stored and the continuation ray (no, nd) with throughput
 // Tn is returned with true.
 __device__ __forceinline__ bool shade_path(const DevScene &sc, uint64_t seed, uint64_t path, int level, int depth_left, uint32_t slot,
-                                           f3 o, f3 d, float4 T, float t, int pslot, float hu, float hv, float4 *hist_e,
-                                           float4 *hist_w, size_t cap, float4 *path_out, f3 &no, f3 &nd, float4 &Tn) {
+                                           f3 o, f3 d, float4 T, float t, int pslot, float hu, float hv, float4 *hist,
+                                           size_t cap, float4 *path_out, f3 &no, f3 &nd, float4 &Tn) {
     if (pslot < 0) { // CpuTracer.cu:124-125: miss -> (1,1,1,1)
-        path_out[slot] = clamp01_4(fold_history(hist_e, hist_w, cap, slot, level, make_float4(1.0f, 1.0f, 1.0f, 1.0f)));
+        path_out[slot] = clamp01_4(fold_history(hist, cap, slot, level, make_float4(1.0f, 1.0f, 1.0f, 1.0f)));
         return false;
     }
     f3 N;
@@ -626,7 +673,7 @@ __device__ __forceinline__ bool shade_path(const DevScene &sc, uint64_t seed, ui
     hit_surface(sc, pslot, t, hu, hv, o, d, N, m);
     float4 e = mul4(m.ke, 32.0f); // CpuTracer.cu:131,185
     if (depth_left < 0) {         // CpuTracer.cu:130-131
-        path_out[slot] = clamp01_4(fold_history(hist_e, hist_w, cap, slot, level, e));
+        path_out[slot] = clamp01_4(fold_history(hist, cap, slot, level, e));
         return false;
     }
     f3 hitInner = o + (t + MI_EPS) * d; // :127
@@ -663,70 +710,78 @@ __device__ __forceinline__ bool shade_path(const DevScene &sc, uint64_t seed, ui
         no = hitOuter; w = m.kd;
     }
     Tn = mul4(w, T); // `w * thresh`, :152,166,174
-    hist_e[(size_t)level * cap + slot] = e;
-    hist_w[(size_t)level * cap + slot] = w;
+    float4 *rec = hist + ((size_t)level * cap + slot) * 2;
+    rec[0] = e;
+    rec[1] = w;
     // entry test of the next level, CpuTracer.cu:121-122
     if ((double)length2_4(Tn) < 3.0 * 12.0 / 255.0 / 255.0) {
-        path_out[slot] = clamp01_4(fold_history(hist_e, hist_w, cap, slot, level + 1, make_float4(0.0f, 0.0f, 0.0f, 0.0f)));
+        path_out[slot] = clamp01_4(fold_history(hist, cap, slot, level + 1, make_float4(0.0f, 0.0f, 0.0f, 0.0f)));
         return false;
     }
     return true;
 }
 
-// One thread per queue entry of level `level`; depth_left = D - level.  PRIMARY = true
-// is level 0: identity queue over the batch's n_fixed slots, ray from primary_ray(),
-// throughput (1,1,1,1) (traceRay(r, 1, depth), CpuTracer.cu:114); slots that are not
-// pixels get a zero path value.
+// One thread per ray of level `level` (stream position i); depth_left = D - level.
+// PRIMARY = true is level 0: the stream is the identity over the batch's n_fixed slots,
+// the ray comes from primary_ray(), throughput (1,1,1,1) (traceRay(r, 1, depth),
+// CpuTracer.cu:114); slots that are not pixels get a zero path value.  Continuation rays
+// are appended to the next level's stream `out`.
 template <bool PRIMARY>
 __global__ void __launch_bounds__(MI_BLOCK)
-k_shade(DevScene sc, ShardGeom g, uint32_t pix0, uint32_t npix, int level, int depth_left, uint64_t seed,
-        const uint32_t *queue, const uint32_t *count_ptr, float4 *ray_o, float4 *ray_d, float4 *thr, const float4 *hits,
-        float4 *hist_e, float4 *hist_w, size_t cap, float4 *path_out, uint32_t *next_queue, uint32_t *next_count, uint32_t n_fixed,
-        const uint32_t *tail_level) {
+k_shade(DevScene sc, ShardGeom g, uint32_t pix0, uint32_t npix, int level, int depth_left, uint64_t seed, RayStream in,
+        const uint32_t *count_ptr, const float4 *hits, float4 *hist, size_t cap, float4 *path_out, RayStream out,
+        uint32_t *next_count, uint32_t n_fixed, const uint32_t *tail_level) {
     if (!PRIMARY && tail_took_over(tail_level, level)) return;
-    const uint32_t n = PRIMARY ? n_fixed : *count_ptr;
+    // i runs over the virtual positions (64 per virtual chunk) of the input stream
+    const uint32_t n_virtual = stream_chunks(PRIMARY ? nullptr : count_ptr, n_fixed) << 6;
     const uint32_t stride = gridDim.x * MI_BLOCK;
-    // every thread of a workgroup runs the same number of iterations (queue_append has barriers)
-    const uint32_t n_round = (n + (MI_BLOCK - 1u)) & ~(MI_BLOCK - 1u);
+    uint32_t *my_count = next_count + (blockIdx.x % MI_SUB) * MI_CNT_STRIDE;
+    const uint32_t out_base = (blockIdx.x % MI_SUB) * out.segcap;
+    // every thread of a workgroup runs the same number of iterations (queue_reserve has barriers)
+    const uint32_t n_round = (n_virtual + (MI_BLOCK - 1u)) & ~(MI_BLOCK - 1u);
     for (uint32_t i = blockIdx.x * MI_BLOCK + threadIdx.x; i < n_round; i += stride) {
         bool alive = false;
-        uint32_t slot = 0;
-        bool live = i < n;
+        uint32_t slot = 0, pos_in = 0;
+        bool live = false;
+        if (i < n_virtual) {
+            uint32_t first, end;
+            stream_chunk(PRIMARY ? nullptr : count_ptr, n_fixed, in.segcap, __builtin_amdgcn_readfirstlane(i >> 6), first, end);
+            pos_in = first + (i & 63u);
+            live = pos_in < end;
+        }
         f3 o = mk3(0, 0, 0), d = mk3(0, 0, 0);
+        float4 T = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
         int px = 0, py = 0;
         uint32_t samp = 0;
         if (live) {
-            slot = PRIMARY ? i : queue[i];
             if (PRIMARY) {
+                slot = pos_in;
                 live = primary_ray(sc, g, pix0, npix, slot, o, d, px, py, samp);
                 if (!live) path_out[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            } else {
+                float4 o4 = in.o[pos_in];
+                slot = (uint32_t)__float_as_int(o4.w);
+                o = xyz(o4);
+                d = xyz(in.d[pos_in]);
+                T = in.thr[pos_in];
+                samp = slot / npix;
+                uint32_t lp = slot - samp * npix;
+                local_to_pixel(g, slot_to_local(g, pix0 + lp), px, py);
             }
         }
+        f3 no = mk3(0, 0, 0), nd = mk3(0, 0, 0);
+        float4 Tn = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         if (live) {
-            float4 h4 = hits[slot];
-            int pslot = __float_as_int(h4.y);
-            float4 T = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
-            if (!PRIMARY) {
-                T = thr[slot];
-                if (pslot >= 0) {
-                    o = xyz(ray_o[slot]);
-                    d = xyz(ray_d[slot]);
-                    samp = slot / npix;
-                    uint32_t lp = slot - samp * npix;
-                    local_to_pixel(g, slot_to_local(g, pix0 + lp), px, py);
-                }
-            }
-            f3 no, nd;
-            float4 Tn;
-            alive = shade_path(sc, seed, path_id(g, px, py, samp), level, depth_left, slot, o, d, T, h4.x, pslot, h4.z, h4.w, hist_e,
-                               hist_w, cap, path_out, no, nd, Tn);
-            if (alive) {
-                ray_o[slot] = make_float4(no.x, no.y, no.z, 0.0f);
-                ray_d[slot] = make_float4(nd.x, nd.y, nd.z, 0.0f);
-                thr[slot] = Tn;
-            }
+            float4 h4 = hits[pos_in];
+            alive = shade_path(sc, seed, path_id(g, px, py, samp), level, depth_left, slot, o, d, T, h4.x, __float_as_int(h4.y), h4.z, h4.w,
+                               hist, cap, path_out, no, nd, Tn);
         }
-        queue_append(alive, slot, next_queue, next_count);
+        const uint32_t pos = out_base + queue_reserve(alive, my_count);
+        if (alive) {
+            out.o[pos] = make_float4(no.x, no.y, no.z, __int_as_float((int)slot));
+            out.d[pos] = make_float4(nd.x, nd.y, nd.z, 0.0f);
+            out.thr[pos] = Tn;
+        }
     }
 }
 
@@ -740,24 +795,23 @@ k_shade(DevScene sc, ShardGeom g, uint32_t pix0, uint32_t npix, int level, int d
 // then publishes its level in *tail_level so the per-level kernels behind it return
 // immediately.  Rays traced beyond the first level are added to *extra_rays.
 __global__ void __launch_bounds__(MI_BLOCK)
-k_tail(DevScene sc, ShardGeom g, uint32_t pix0, uint32_t npix, int level0, int depth_total, uint64_t seed, const uint32_t *queue,
-       const uint32_t *count_ptr, uint32_t threshold, uint32_t *tail_level, const float4 *ray_o, const float4 *ray_d, const float4 *thr,
-       float4 *hist_e, float4 *hist_w, size_t cap, float4 *path_out, int *ovf, unsigned long long *extra_rays, int leaf_min,
-       int shade_min) {
+k_tail(DevScene sc, ShardGeom g, uint32_t pix0, uint32_t npix, int level0, int depth_total, uint64_t seed, RayStream in,
+       const uint32_t *count_ptr, uint32_t threshold, uint32_t *tail_level, float4 *hist, size_t cap, float4 *path_out, int *ovf,
+       unsigned long long *extra_rays, int leaf_min, int shade_min) {
     __shared__ int lds_stack[MI_LDS_STACK * MI_BLOCK];
-    const uint32_t n = *count_ptr;
+    const uint32_t n = stream_total(count_ptr);
     const uint32_t tl = *tail_level;
     // same decision in every wave: tl is only ever written with level0 by this launch
     if (n == 0 || n > threshold || (tl != 0 && tl != (uint32_t)level0)) return;
     const int lane = threadIdx.x & 63;
     if (blockIdx.x == 0 && threadIdx.x == 0) *tail_level = (uint32_t)level0;
-    int *stack = lds_stack + threadIdx.x;
+    lds_int *stack = (lds_int *)lds_stack + threadIdx.x;
     const size_t ovf_stride = (size_t)gridDim.x * MI_BLOCK;
     int *my_ovf = ovf + (size_t)blockIdx.x * MI_BLOCK + threadIdx.x;
     const uint32_t n_waves = gridDim.x * (MI_BLOCK / 64);
     const uint32_t wave_id = __builtin_amdgcn_readfirstlane(blockIdx.x * (MI_BLOCK / 64) + (threadIdx.x >> 6));
-    const uint32_t n_chunks = (n + 63u) >> 6;
-    uint32_t chunk = wave_id;           // static interleaved chunks: wave w takes w, w+W, ... (wave-uniform)
+    const uint32_t n_chunks = stream_chunks(count_ptr, 0u);
+    uint32_t chunk = wave_id;           // static interleaved virtual chunks: wave w takes w, w+W, ... (wave-uniform)
     uint32_t rng_next = 0, rng_end = 0; // wave-uniform, in rays
     uint32_t n_extra = 0;               // wave-uniform
 
@@ -774,19 +828,21 @@ k_tail(DevScene sc, ShardGeom g, uint32_t pix0, uint32_t npix, int level0, int d
     do {              // single back edge, no `continue` (see k_extend)
         const int n_idle = 64 - __popcll(act);
         if (more && (n_idle >= 16 || act == 0ull)) {
-            if (rng_next >= rng_end && chunk < n_chunks) { // chunk < n_chunks  =>  chunk*64 < n
-                rng_next = chunk << 6;
-                rng_end = ((chunk + 1) << 6) < n ? ((chunk + 1) << 6) : n;
+            if (rng_next >= rng_end && chunk < n_chunks) {
+                stream_chunk(count_ptr, 0u, in.segcap, chunk, rng_next, rng_end);
+                rng_next = __builtin_amdgcn_readfirstlane(rng_next);
+                rng_end = __builtin_amdgcn_readfirstlane(rng_end);
                 chunk += n_waves;
             }
             if (rng_next < rng_end) {
                 const uint32_t rank = (uint32_t)__popcll(~act & ((1ull << lane) - 1ull));
                 const uint32_t avail = rng_end - rng_next;
                 if (!active && rank < avail) {
-                    slot = queue[rng_next + rank];
-                    T = thr[slot];
+                    const float4 o4 = in.o[rng_next + rank];
+                    slot = (uint32_t)__float_as_int(o4.w);
+                    T = in.thr[rng_next + rank];
                     level = level0;
-                    lane_start(sc, L, xyz(ray_o[slot]), xyz(ray_d[slot]));
+                    lane_start(sc, L, xyz(o4), xyz(in.d[rng_next + rank]));
                     active = true;
                 }
                 rng_next += (uint32_t)n_idle < avail ? (uint32_t)n_idle : avail;
@@ -807,7 +863,7 @@ k_tail(DevScene sc, ShardGeom g, uint32_t pix0, uint32_t npix, int level0, int d
                 f3 no, nd;
                 float4 Tn;
                 cont = shade_path(sc, seed, path_id(g, px, py, samp), level, depth_total - level, slot, L.o, L.d, T, L.h.t, L.h.slot, L.h.u,
-                                  L.h.v, hist_e, hist_w, cap, path_out, no, nd, Tn);
+                                  L.h.v, hist, cap, path_out, no, nd, Tn);
                 if (cont) {
                     T = Tn;
                     level++;

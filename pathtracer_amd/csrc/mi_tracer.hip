@@ -60,8 +60,9 @@ struct mi_ctx {
     DevScene sc{};
     uint32_t n_nodes = 0;
     DevBuf nodes, tri, tri_normal, tri_mat, tri_has_vmat, sph, sph_mat, mats, prim_id;
-    // per-batch path state (sized by slot capacity / depth)
-    DevBuf ray_o, ray_d, thr, hits, path_out, hist_e, hist_w, queue_a, queue_b, counters, ovf, totals;
+    // per-batch path state (sized by slot capacity / depth): two ray streams (level k reads
+    // stream k&1 and writes stream (k+1)&1), hits by stream position, history and path value by slot
+    DevBuf ray_o[2], ray_d[2], thr[2], hits, path_out, hist, counters, ovf, totals;
     // outputs for the host-pointer entry points
     DevBuf out_mean, out_rgba8, out_rgb8, probe_i, probe_t, probe_n;
     std::vector<hipEvent_t> ev;
@@ -69,7 +70,6 @@ struct mi_ctx {
     // tuning knobs (defaults measured on MI355X, overridable through the environment)
     int extend_wg_per_cu = 6;   // MI_TRACER_EXTEND_WG_PER_CU: persistent workgroups of k_extend per CU
     int refill_min = 20;        // MI_TRACER_REFILL: idle lanes that trigger a refill
-    uint32_t static_eighths = 8; // MI_TRACER_STATIC_EIGHTHS: share of chunks dealt statically, in 1/8
     int leaf_min = 16;          // MI_TRACER_LEAF_MIN: lanes with a pending leaf that trigger a leaf phase
     int shade_min = 24;         // MI_TRACER_SHADE_MIN: lanes waiting to be shaded that trigger a shade phase of k_tail
     int tail_threshold = 1500000; // MI_TRACER_TAIL: k_tail takes over a batch once a level has at most this many rays (0 = off)
@@ -80,6 +80,9 @@ static const int kMaxLevels = 64; // counters reserved per batch (depth + 2 must
 // (+0 node visits, +1 primitive tests, +2 max steps of a ray, +3/+4 wave iterations
 // total/max, +5 rays k_tail traced beyond its first level, +8..+47 visits per tree depth)
 static const int kTotals = 64;
+// counters: cnt[level][MI_SUB] ray counts of the sub-streams of each level, then the tail_level word
+static const int kLevelWords = MI_SUB * MI_CNT_STRIDE; // counter j of a level at word j * MI_CNT_STRIDE
+static const int kCounterWords = (kMaxLevels + 1) * kLevelWords + MI_CNT_STRIDE;
 
 static int extend_grid(const mi_ctx *c) { return c->n_cu * c->extend_wg_per_cu; }
 
@@ -111,7 +114,6 @@ MI_API mi_status mi_ctx_create(int device_id, mi_ctx **out) {
     c->leaf_min = env_int("MI_TRACER_LEAF_MIN", 1, 64, c->leaf_min);
     c->shade_min = env_int("MI_TRACER_SHADE_MIN", 1, 64, c->shade_min);
     c->tail_threshold = env_int("MI_TRACER_TAIL", 0, 1 << 30, c->tail_threshold);
-    c->static_eighths = (uint32_t)env_int("MI_TRACER_STATIC_EIGHTHS", 0, 8, (int)c->static_eighths);
     hipError_t es = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (es != hipSuccess) { delete c; return fail(MI_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(es)); }
     es = hipHostMalloc((void **)&c->h_totals, kTotals * sizeof(uint64_t), hipHostMallocDefault);
@@ -125,8 +127,8 @@ MI_API void mi_ctx_destroy(mi_ctx *c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     DevBuf *all[] = {&c->nodes, &c->tri, &c->tri_normal, &c->tri_mat, &c->tri_has_vmat, &c->sph, &c->sph_mat, &c->mats,
-                     &c->prim_id, &c->ray_o, &c->ray_d, &c->thr, &c->hits, &c->path_out, &c->hist_e, &c->hist_w,
-                     &c->queue_a, &c->queue_b, &c->counters, &c->ovf, &c->totals, &c->out_mean, &c->out_rgba8,
+                     &c->prim_id, &c->ray_o[0], &c->ray_o[1], &c->ray_d[0], &c->ray_d[1], &c->thr[0], &c->thr[1], &c->hits,
+                     &c->path_out, &c->hist, &c->counters, &c->ovf, &c->totals, &c->out_mean, &c->out_rgba8,
                      &c->out_rgb8, &c->probe_i, &c->probe_t, &c->probe_n};
     for (DevBuf *b : all) b->release();
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
@@ -281,8 +283,10 @@ __global__ void k_sum_counts(const uint32_t *counts, int n, uint64_t *totals, co
         uint64_t s = 0, ext = 0;
         const uint32_t tl = *tail_level; // 0, or the level k_tail took over at
         for (int i = 0; i < n; i++) {
-            s += counts[i];
-            if (tl == 0 || (uint32_t)i < tl) ext += counts[i];
+            uint64_t c = 0;
+            for (int j = 0; j < MI_SUB; j++) c += counts[(i * MI_SUB + j) * MI_CNT_STRIDE];
+            s += c;
+            if (tl == 0 || (uint32_t)i < tl) ext += c;
         }
         totals[8] += ext; // rays traced by k_extend launches
         totals[0] += s + totals[7]; // rays cast = sum of extend queue lengths + rays k_tail traced beyond its first level
@@ -312,16 +316,24 @@ MI_API mi_status mi_render_device(mi_ctx *c, const mi_render_params *p, void *d_
     const size_t cap = (size_t)cap64;
     const int hist_levels = std::max(1, p->depth + 1);
     const bool count_work = p->count_work != 0;
-    HIPCHK(c->ray_o.ensure(cap * 16));
-    HIPCHK(c->ray_d.ensure(cap * 16));
-    HIPCHK(c->thr.ensure(cap * 16));
-    HIPCHK(c->hits.ensure(cap * 16));
+    // Ray streams: MI_SUB sub-streams of `segcap` positions each.  Shade workgroup b appends to
+    // sub-stream b % MI_SUB and handles at most
+    // ceil((n_virtual + 255) / sgrid) + 256 rays (grid-stride loop over 256-ray groups), n_virtual <= cap + 64*MI_SUB.
+    const int sgrid = (int)std::min<int64_t>((int64_t)c->n_cu * 8, (int64_t)(cap + MI_BLOCK - 1) / MI_BLOCK);
+    const size_t wg_per_sub = ((size_t)sgrid + MI_SUB - 1) / MI_SUB;
+    const size_t segcap64 = (wg_per_sub * ((cap + 64 * MI_SUB + MI_BLOCK + (size_t)sgrid - 1) / (size_t)sgrid + MI_BLOCK) + 63) / 64 * 64;
+    if (segcap64 * MI_SUB >= ((size_t)1 << 32)) return fail(MI_ERR_INVALID, "batch too large for 32-bit stream positions");
+    const uint32_t segcap = (uint32_t)segcap64;
+    const size_t stream_cap = segcap64 * MI_SUB;
+    for (int i = 0; i < 2; i++) {
+        HIPCHK(c->ray_o[i].ensure(stream_cap * 16));
+        HIPCHK(c->ray_d[i].ensure(stream_cap * 16));
+        HIPCHK(c->thr[i].ensure(stream_cap * 16));
+    }
+    HIPCHK(c->hits.ensure(stream_cap * 16));
     HIPCHK(c->path_out.ensure(cap * 16));
-    HIPCHK(c->hist_e.ensure(cap * 16 * hist_levels));
-    HIPCHK(c->hist_w.ensure(cap * 16 * hist_levels));
-    HIPCHK(c->queue_a.ensure(cap * 4));
-    HIPCHK(c->queue_b.ensure(cap * 4));
-    HIPCHK(c->counters.ensure((2 * (kMaxLevels + 1) + 2) * 4));
+    HIPCHK(c->hist.ensure(cap * 32 * hist_levels));
+    HIPCHK(c->counters.ensure(kCounterWords * 4));
     const int egrid = extend_grid(c);
     HIPCHK(c->ovf.ensure((size_t)(MI_MAX_STACK - MI_LDS_STACK) * egrid * MI_BLOCK * 4));
     HIPCHK(c->totals.ensure(kTotals * 8));
@@ -331,33 +343,31 @@ MI_API mi_status mi_render_device(mi_ctx *c, const mi_render_params *p, void *d_
     mi_status es = get_events(c, per_launch ? n_ev : 2);
     if (es != MI_OK) return es;
 
-    uint32_t *cnt = c->counters.as<uint32_t>();          // cnt[k] = queue length at level k
-    uint32_t *cur = cnt + (kMaxLevels + 1);              // cur[k] = work cursor of extend at level k
-    uint32_t *tail_level = cnt + 2 * (kMaxLevels + 1);    // 0, or the level at which k_tail took over
-    uint32_t *qa = c->queue_a.as<uint32_t>(), *qb = c->queue_b.as<uint32_t>();
+    uint32_t *cnt = c->counters.as<uint32_t>();               // cnt[k*kLevelWords + j*MI_CNT_STRIDE] = rays in sub-stream j of level k
+    uint32_t *tail_level = cnt + (kMaxLevels + 1) * kLevelWords;  // 0, or the level at which k_tail took over
+    const RayStream rs[2] = {{c->ray_o[0].as<float4>(), c->ray_d[0].as<float4>(), c->thr[0].as<float4>(), segcap},
+                             {c->ray_o[1].as<float4>(), c->ray_d[1].as<float4>(), c->thr[1].as<float4>(), segcap}};
     HIPCHK(hipMemsetAsync(c->totals.p, 0, kTotals * 8, st));
     HIPCHK(hipEventRecord(c->ev[0], st));
     size_t evi = 2;
-    const int sgrid = std::min<int64_t>((int64_t)c->n_cu * 8, (cap + MI_BLOCK - 1) / MI_BLOCK);
     for (int64_t b = 0; b < n_batches; b++) {
         const uint32_t pix0 = (uint32_t)(b * npix_b);
         const uint32_t np = (uint32_t)std::min<int64_t>(npix_b, local - (int64_t)pix0);
         const int64_t nslots = (int64_t)np * spp;
-        HIPCHK(hipMemsetAsync(cnt, 0, (2 * (kMaxLevels + 1) + 2) * 4, st));
+        HIPCHK(hipMemsetAsync(cnt, 0, kCounterWords * 4, st));
         for (int k = 0; k < levels; k++) {
-            uint32_t *qin = (k & 1) ? qb : qa, *qout = (k & 1) ? qa : qb;
+            const RayStream &sin = rs[k & 1], &sout = rs[(k + 1) & 1];
             unsigned long long *ws = count_work ? c->totals.as<unsigned long long>() + 2 : nullptr;
             if (per_launch) HIPCHK(hipEventRecord(c->ev[evi++], st)); // 4 events per level: tail | extend | shade
             if (k >= 1 && c->tail_threshold > 0 && !count_work)
-                hipLaunchKernelGGL(k_tail, dim3(egrid), dim3(MI_BLOCK), 0, st, c->sc, g, pix0, np, k, p->depth, p->seed, qin, cnt + k,
-                                   (uint32_t)c->tail_threshold, tail_level, c->ray_o.as<float4>(), c->ray_d.as<float4>(), c->thr.as<float4>(),
-                                   c->hist_e.as<float4>(), c->hist_w.as<float4>(), cap, c->path_out.as<float4>(), c->ovf.as<int>(),
+                hipLaunchKernelGGL(k_tail, dim3(egrid), dim3(MI_BLOCK), 0, st, c->sc, g, pix0, np, k, p->depth, p->seed, sin, cnt + k * kLevelWords,
+                                   (uint32_t)c->tail_threshold, tail_level, c->hist.as<float4>(), cap, c->path_out.as<float4>(), c->ovf.as<int>(),
                                    c->totals.as<unsigned long long>() + 7, c->leaf_min, c->shade_min);
             if (per_launch) HIPCHK(hipEventRecord(c->ev[evi++], st));
 #define MI_EXTEND_ARGS(PRIM)                                                                                                   \
-    dim3(egrid), dim3(MI_BLOCK), 0, st, c->sc, (PRIM) ? (const uint32_t *)nullptr : qin, (PRIM) ? (const uint32_t *)nullptr : cnt + k,      \
-        (PRIM) ? (uint32_t)nslots : 0u, cur + k, c->ray_o.as<float4>(), c->ray_d.as<float4>(), c->hits.as<float4>(), c->ovf.as<int>(), ws, \
-        c->refill_min, c->static_eighths, c->leaf_min, g, pix0, np, cnt, tail_level, k
+    dim3(egrid), dim3(MI_BLOCK), 0, st, c->sc, (PRIM) ? (const uint32_t *)nullptr : cnt + k * kLevelWords,                   \
+        (PRIM) ? (uint32_t)nslots : 0u, segcap, sin.o, sin.d, c->hits.as<float4>(), c->ovf.as<int>(), ws,                          \
+        c->refill_min, c->leaf_min, g, pix0, np, cnt, tail_level, k
             if (k == 0) {
                 if (count_work) hipLaunchKernelGGL((k_extend<true, true>), MI_EXTEND_ARGS(true));
                 else hipLaunchKernelGGL((k_extend<false, true>), MI_EXTEND_ARGS(true));
@@ -368,9 +378,8 @@ MI_API mi_status mi_render_device(mi_ctx *c, const mi_render_params *p, void *d_
 #undef MI_EXTEND_ARGS
             if (per_launch) HIPCHK(hipEventRecord(c->ev[evi++], st));
 #define MI_SHADE_ARGS                                                                                                          \
-    dim3(sgrid), dim3(MI_BLOCK), 0, st, c->sc, g, pix0, np, k, p->depth - k, p->seed, qin, cnt + k, c->ray_o.as<float4>(),       \
-        c->ray_d.as<float4>(), c->thr.as<float4>(), c->hits.as<float4>(), c->hist_e.as<float4>(), c->hist_w.as<float4>(), cap, \
-        c->path_out.as<float4>(), qout, cnt + k + 1, (uint32_t)nslots, tail_level
+    dim3(sgrid), dim3(MI_BLOCK), 0, st, c->sc, g, pix0, np, k, p->depth - k, p->seed, sin, cnt + k * kLevelWords, c->hits.as<float4>(),         \
+        c->hist.as<float4>(), cap, c->path_out.as<float4>(), sout, cnt + (k + 1) * kLevelWords, (uint32_t)nslots, tail_level
             if (k == 0) hipLaunchKernelGGL(k_shade<true>, MI_SHADE_ARGS);
             else hipLaunchKernelGGL(k_shade<false>, MI_SHADE_ARGS);
 #undef MI_SHADE_ARGS
@@ -414,8 +423,9 @@ MI_API mi_status mi_render_device(mi_ctx *c, const mi_render_params *p, void *d_
                 stats->extend_launches++;
             }
             if (getenv("MI_TRACER_DEBUG_LEVELS")) { // per-launch timings and queue lengths, for tuning only
-                std::vector<uint32_t> hc(kMaxLevels + 1);
-                (void)hipMemcpy(hc.data(), cnt, hc.size() * 4, hipMemcpyDeviceToHost); // counts of the LAST batch
+                std::vector<uint32_t> hs((kMaxLevels + 1) * kLevelWords), hc(kMaxLevels + 1, 0u);
+                (void)hipMemcpy(hs.data(), cnt, hs.size() * 4, hipMemcpyDeviceToHost); // counts of the LAST batch
+                for (size_t i = 0; i < hs.size(); i += MI_CNT_STRIDE) hc[i / kLevelWords] += hs[i];
                 size_t j = 2;
                 for (int64_t b = 0; b < n_batches; b++)
                     for (int k = 0; k < levels; k++, j += 4) {
@@ -492,14 +502,12 @@ MI_API mi_status mi_assemble_rgb8(mi_ctx *c, const mi_render_params *p, const vo
 // Shared tail of the two probes: extend over n rays already in ray_o/ray_d, copy out.
 static mi_status probe_chunk(mi_ctx *c, int64_t n, int32_t *prim_id_out, float *t_out, float *n_out) {
     hipStream_t st = c->stream;
-    uint32_t *cur = c->counters.as<uint32_t>();
-    HIPCHK(hipMemsetAsync(cur, 0, 4, st));
-    hipLaunchKernelGGL((k_extend<false, false>), dim3(extend_grid(c)), dim3(MI_BLOCK), 0, st, c->sc, (const uint32_t *)nullptr,
-                       (const uint32_t *)nullptr, (uint32_t)n, cur, c->ray_o.as<float4>(), c->ray_d.as<float4>(), c->hits.as<float4>(),
-                       c->ovf.as<int>(), (unsigned long long *)nullptr, c->refill_min, c->static_eighths, c->leaf_min, ShardGeom{}, 0u, 1u,
+    hipLaunchKernelGGL((k_extend<false, false>), dim3(extend_grid(c)), dim3(MI_BLOCK), 0, st, c->sc,
+                       (const uint32_t *)nullptr, (uint32_t)n, 0u, c->ray_o[0].as<float4>(), c->ray_d[0].as<float4>(), c->hits.as<float4>(),
+                       c->ovf.as<int>(), (unsigned long long *)nullptr, c->refill_min, c->leaf_min, ShardGeom{}, 0u, 1u,
                        (uint32_t *)nullptr, (const uint32_t *)nullptr, 0);
-    hipLaunchKernelGGL(k_probe_out, dim3((unsigned)((n + MI_BLOCK - 1) / MI_BLOCK)), dim3(MI_BLOCK), 0, st, c->sc, n, c->ray_o.as<float4>(),
-                       c->ray_d.as<float4>(), c->hits.as<float4>(), c->probe_i.as<int32_t>(), c->probe_t.as<float>(),
+    hipLaunchKernelGGL(k_probe_out, dim3((unsigned)((n + MI_BLOCK - 1) / MI_BLOCK)), dim3(MI_BLOCK), 0, st, c->sc, n, c->ray_o[0].as<float4>(),
+                       c->ray_d[0].as<float4>(), c->hits.as<float4>(), c->probe_i.as<int32_t>(), c->probe_t.as<float>(),
                        n_out ? c->probe_n.as<float>() : nullptr);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(prim_id_out, c->probe_i.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
@@ -510,13 +518,12 @@ static mi_status probe_chunk(mi_ctx *c, int64_t n, int32_t *prim_id_out, float *
 }
 
 static mi_status probe_alloc(mi_ctx *c, size_t chunk) {
-    HIPCHK(c->ray_o.ensure(chunk * 16));
-    HIPCHK(c->ray_d.ensure(chunk * 16));
+    HIPCHK(c->ray_o[0].ensure(chunk * 16));
+    HIPCHK(c->ray_d[0].ensure(chunk * 16));
     HIPCHK(c->hits.ensure(chunk * 16));
     HIPCHK(c->probe_i.ensure(chunk * 4));
     HIPCHK(c->probe_t.ensure(chunk * 4));
     HIPCHK(c->probe_n.ensure(chunk * 12));
-    HIPCHK(c->counters.ensure(2 * (kMaxLevels + 1) * 4));
     HIPCHK(c->ovf.ensure((size_t)(MI_MAX_STACK - MI_LDS_STACK) * extend_grid(c) * MI_BLOCK * 4));
     return MI_OK;
 }
@@ -533,7 +540,7 @@ MI_API mi_status mi_trace_primary(mi_ctx *c, int32_t width, int32_t height, int3
     for (int64_t first = 0; first < total; first += chunk) {
         int64_t n = std::min(chunk, total - first);
         hipLaunchKernelGGL(k_generate_primary, dim3((unsigned)((n + MI_BLOCK - 1) / MI_BLOCK)), dim3(MI_BLOCK), 0, c->stream, c->sc, width, height,
-                           samples, first, n, c->ray_o.as<float4>(), c->ray_d.as<float4>());
+                           samples, first, n, c->ray_o[0].as<float4>(), c->ray_d[0].as<float4>());
         mi_status ps = probe_chunk(c, n, prim_id_out + first, t_out + first, n_out ? n_out + 3 * first : nullptr);
         if (ps != MI_OK) return ps;
     }
@@ -556,8 +563,8 @@ MI_API mi_status mi_trace_rays(mi_ctx *c, int64_t total, const float *rays, int3
             o4[4 * i] = r[0]; o4[4 * i + 1] = r[1]; o4[4 * i + 2] = r[2]; o4[4 * i + 3] = 0;
             d4[4 * i] = r[3]; d4[4 * i + 1] = r[4]; d4[4 * i + 2] = r[5]; d4[4 * i + 3] = 0;
         }
-        HIPCHK(hipMemcpyAsync(c->ray_o.p, o4.data(), (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(hipMemcpyAsync(c->ray_d.p, d4.data(), (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->ray_o[0].p, o4.data(), (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->ray_d[0].p, d4.data(), (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
         mi_status ps = probe_chunk(c, n, prim_id_out + first, t_out + first, n_out ? n_out + 3 * first : nullptr);
         if (ps != MI_OK) return ps;
     }

@@ -52,7 +52,7 @@ class Scene:
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
-        if h:
+        if h and N is not None and getattr(N, "host", None) is not None:  # module globals may be gone at interpreter exit
             N.host.pt_scene_free(h)
 
     @property

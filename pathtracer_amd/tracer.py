@@ -24,7 +24,7 @@ class Context:
 
     def close(self):
         h, self._h = getattr(self, "_h", None), None
-        if h:
+        if h and N is not None and getattr(N, "mi", None) is not None:  # module globals may be gone at interpreter exit
             N.mi.mi_ctx_destroy(h)
 
     __del__ = close
