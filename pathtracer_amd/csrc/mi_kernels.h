@@ -175,7 +175,7 @@ __device__ __forceinline__ uint32_t queue_reserve(bool alive, uint32_t *count) {
 // sub-stream b % MI_SUB.  Consumers walk a VIRTUAL sequence of 64-ray chunks, the chunks
 // of sub-stream 0 first, then 1, ...; stream_chunk() maps a virtual chunk to its rays.
 #ifndef MI_SUB
-#define MI_SUB 16
+#define MI_SUB 8
 #endif
 #define MI_CNT_STRIDE 32 // words between counters: every counter word has a 128-B line of its own
 struct RayStream {
