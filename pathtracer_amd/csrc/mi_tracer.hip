@@ -72,6 +72,7 @@ struct mi_ctx {
     int refill_min = 20;        // MI_TRACER_REFILL: idle lanes that trigger a refill
     int leaf_min = 16;          // MI_TRACER_LEAF_MIN: lanes with a pending leaf that trigger a leaf phase
     int shade_min = 24;         // MI_TRACER_SHADE_MIN: lanes waiting to be shaded that trigger a shade phase of k_tail
+    int tail_wg_per_cu = 4;     // workgroups of k_tail resident per CU (occupancy query at context creation)
     int tail_threshold = 1500000; // MI_TRACER_TAIL: k_tail takes over a batch once a level has at most this many rays (0 = off)
 };
 
@@ -114,6 +115,12 @@ MI_API mi_status mi_ctx_create(int device_id, mi_ctx **out) {
     c->leaf_min = env_int("MI_TRACER_LEAF_MIN", 1, 64, c->leaf_min);
     c->shade_min = env_int("MI_TRACER_SHADE_MIN", 1, 64, c->shade_min);
     c->tail_threshold = env_int("MI_TRACER_TAIL", 0, 1 << 30, c->tail_threshold);
+    // k_tail is persistent and deals its work statically over the grid: launch exactly as many
+    // workgroups as are resident at once (a second round would start after the first has finished)
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_tail, MI_BLOCK, 0) == hipSuccess && occ > 0)
+        c->tail_wg_per_cu = std::min(occ, c->extend_wg_per_cu);
+    c->tail_wg_per_cu = env_int("MI_TRACER_TAIL_WG_PER_CU", 1, 16, c->tail_wg_per_cu);
     hipError_t es = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (es != hipSuccess) { delete c; return fail(MI_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(es)); }
     es = hipHostMalloc((void **)&c->h_totals, kTotals * sizeof(uint64_t), hipHostMallocDefault);
@@ -360,7 +367,7 @@ MI_API mi_status mi_render_device(mi_ctx *c, const mi_render_params *p, void *d_
             unsigned long long *ws = count_work ? c->totals.as<unsigned long long>() + 2 : nullptr;
             if (per_launch) HIPCHK(hipEventRecord(c->ev[evi++], st)); // 4 events per level: tail | extend | shade
             if (k >= 1 && c->tail_threshold > 0 && !count_work)
-                hipLaunchKernelGGL(k_tail, dim3(egrid), dim3(MI_BLOCK), 0, st, c->sc, g, pix0, np, k, p->depth, p->seed, sin, cnt + k * kLevelWords,
+                hipLaunchKernelGGL(k_tail, dim3(c->n_cu * c->tail_wg_per_cu), dim3(MI_BLOCK), 0, st, c->sc, g, pix0, np, k, p->depth, p->seed, sin, cnt + k * kLevelWords,
                                    (uint32_t)c->tail_threshold, tail_level, c->hist.as<float4>(), cap, c->path_out.as<float4>(), c->ovf.as<int>(),
                                    c->totals.as<unsigned long long>() + 7, c->leaf_min, c->shade_min);
             if (per_launch) HIPCHK(hipEventRecord(c->ev[evi++], st));
