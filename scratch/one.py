@@ -1,4 +1,4 @@
-import sys, os; sys.path.insert(0,'.')
+import sys, os; sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT','.'))
 import pathtracer_amd as P
 from pathtracer_amd import scenes as S
 sc=S.blob_scene(6); w,h=sc.image_size(1920)

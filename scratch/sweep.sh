@@ -1,5 +1,5 @@
 set -e
-for cfg in "MI_TRACER_TAIL=5000000" "MI_TRACER_TAIL_WG_PER_CU=3" "MI_TRACER_TAIL_WG_PER_CU=2" "MI_TRACER_SHADE_MIN=16" "MI_TRACER_SHADE_MIN=32" "MI_TRACER_TAIL=800000" "MI_TRACER_TAIL=2500000"; do
+for cfg in "MI_TRACER_EXTEND_WG_PER_CU=6" "MI_TRACER_EXTEND_WG_PER_CU=7" "MI_TRACER_EXTEND_WG_PER_CU=8" "MI_TRACER_EXTEND_WG_PER_CU=5" "MI_TRACER_REFILL=12" "MI_TRACER_REFILL=28"; do
   echo "== $cfg"
-  env $cfg timeout -k 10 60 python scratch/dbg.py 2>&1 | tail -1
+  env $cfg MI_TRACER_DEBUG_LEVELS=1 timeout -k 10 60 python scratch/dbg.py 2>&1 | tail -1
 done

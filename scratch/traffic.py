@@ -4,7 +4,7 @@ usage: python scratch/traffic.py <fetch_dir> <write_dir> <workload> <steps_profi
 import csv, glob, json, os, sys
 fetch_dir, write_dir, workload = sys.argv[1:4]
 def kb(d, counter):
-    f = glob.glob(f"{d}/*/*counter_collection.csv")[0]
+    f = (glob.glob(f"{d}/*/*counter_collection.csv") + glob.glob(f"{d}/*counter_collection.csv"))[0]
     tot, n = 0.0, 0
     for r in csv.DictReader(open(f)):
         if "k_extend<false" in r["Kernel_Name"] and r["Counter_Name"] == counter:
