@@ -190,6 +190,18 @@ mi_status mi_trace_primary(mi_ctx *ctx, int32_t width, int32_t height,
 mi_status mi_trace_rays(mi_ctx *ctx, int64_t n, const float *rays,
                         int32_t *prim_id_out, float *t_out, float *n_out);
 
+/* Any-hit (occlusion) query: occluded_out[i] = 1 iff some primitive's intersect() accepts
+ * ray i when the running closest distance starts at tmax[i] (triangle: 0 < t <= tmax,
+ * trimesh.cu:92-96; sphere: the accepted root < tmax, sphere.cu:17-28), 0 otherwise.  The
+ * traversal stops at the first accepted primitive.  tmax above ISECT_NO_HIT (12345678.9f,
+ * ray.h:14 — the distance every reference query starts with) or NaN is clamped to it: with an
+ * infinite bound the triangle test would accept t = inf of plane-parallel rays.  NO counterpart in the reference, which
+ * has no shadow rays (lights are emissive geometry, Parser.cu:650-651); it is the "shadow
+ * any-hit" of the north star, outside the parity renderer, checked against the oracle's
+ * test of every primitive.  rays: float[n*6] HOST, tmax: float[n] HOST, out: uint8[n] HOST. */
+mi_status mi_occluded_rays(mi_ctx *ctx, int64_t n, const float *rays, const float *tmax,
+                           uint8_t *occluded_out);
+
 /* Thread-local description of the last error returned on this thread. */
 const char *mi_last_error(void);
 

@@ -509,6 +509,29 @@ ORC_API int orc_trace_rays(const mi_scene_soa *s, int64_t n, const float *rays, 
     return 0;
 }
 
+/* Any-hit: does ANY primitive's intersect() accept the ray when the running closest
+ * distance starts at tmax (trimesh.cu:92-96 accepts t <= best, sphere.cu:22-28 t < best)?
+ * No counterpart in the reference (it casts no shadow rays); checker for
+ * mi_occluded_rays.  Every primitive is tested with a fresh isect. */
+ORC_API int orc_occluded(const mi_scene_soa *s, int64_t n, const float *rays, const float *tmax, uint8_t *out) {
+    if (!s || n < 0 || !rays || !tmax || !out) return 1;
+    SceneView sc{s};
+    Counters c;
+    const int64_t n_prim = (int64_t)s->n_tri + s->n_sph;
+    for (int64_t k = 0; k < n; k++) {
+        const float *q = rays + 6 * k;
+        Ray r(f4(q[0], q[1], q[2]), f4(q[3], q[4], q[5]));
+        uint8_t occ = 0;
+        for (int64_t slot = 0; slot < n_prim && !occ; slot++) {
+            Isect is;
+            is.t = tmax[k] < ISECT_NO_HIT ? tmax[k] : ISECT_NO_HIT; /* clamped to ray.h:14, as mi_occluded_rays documents */
+            if (prim_intersect(sc, (int)slot, r, is, false, c)) occ = 1;
+        }
+        out[k] = occ;
+    }
+    return 0;
+}
+
 /* Full render with CpuTracer's scheduling shape (CpuTracer.cu:57-97: LIFO list of
  * 32x32 tiles behind a mutex, `threads` workers; :188-191 join).  Only tiles with
  * (row-major tile index) % shard_count == shard_rank are rendered; other pixels

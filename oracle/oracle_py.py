@@ -25,6 +25,7 @@ class Counters(C.Structure):
 
 lib.orc_trace_primary.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Counters)]
 lib.orc_trace_rays.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Counters)]
+lib.orc_occluded.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
 lib.orc_render.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(Counters)]
 lib.orc_tri_precompute.argtypes = [C.c_void_p] * 5
 lib.orc_camera_from_look.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -59,6 +60,15 @@ def trace_rays(scene, rays, mode=BRUTE):
     rc = lib.orc_trace_rays(_soa_ptr(scene), n, rays.ctypes.data, mode, ids.ctypes.data, t.ctypes.data, nrm.ctypes.data, C.byref(cnt))
     assert rc == 0
     return ids, t, nrm, cnt
+
+
+def occluded(scene, rays, tmax):
+    rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
+    tmax = np.ascontiguousarray(tmax, np.float32).reshape(-1)
+    out = np.empty(len(rays), np.uint8)
+    rc = lib.orc_occluded(_soa_ptr(scene), len(rays), rays.ctypes.data, tmax.ctypes.data, out.ctypes.data)
+    assert rc == 0
+    return out
 
 
 def render(scene, params, sincos=SINCOS_POLY, mode=BVH_CANONICAL, threads=0, rows=None):

@@ -62,7 +62,7 @@ class Stats(C.Structure):
 
 MI_SYMBOLS = [
     "mi_ctx_create", "mi_ctx_destroy", "mi_scene_upload", "mi_render", "mi_render_device", "mi_shard_pixels",
-    "mi_assemble_rgb8", "mi_trace_primary", "mi_trace_rays", "mi_last_error", "mi_abi_version",
+    "mi_assemble_rgb8", "mi_trace_primary", "mi_trace_rays", "mi_occluded_rays", "mi_last_error", "mi_abi_version",
 ]
 
 
@@ -94,6 +94,8 @@ mi.mi_trace_primary.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c
 mi.mi_trace_primary.restype = C.c_int
 mi.mi_trace_rays.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
 mi.mi_trace_rays.restype = C.c_int
+mi.mi_occluded_rays.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+mi.mi_occluded_rays.restype = C.c_int
 mi.mi_last_error.restype = C.c_char_p
 mi.mi_abi_version.restype = C.c_int
 

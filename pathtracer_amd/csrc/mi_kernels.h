@@ -379,7 +379,7 @@ struct Lane {
     int cur, sp, pend0, pend1;
     bool exact;
 };
-__device__ __forceinline__ void lane_start(const DevScene &sc, Lane &L, f3 o, f3 d) {
+__device__ __forceinline__ void lane_start(const DevScene &sc, Lane &L, f3 o, f3 d, float t0 = MI_NO_HIT) {
     L.o = o;
     L.d = d;
     L.inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z); // ray.h:53-57,79-82
@@ -387,7 +387,7 @@ __device__ __forceinline__ void lane_start(const DevScene &sc, Lane &L, f3 o, f3
     // fast slab path only when nothing can overflow to inf/NaN (the comparisons are false for NaN)
     L.exact = !(__builtin_fabsf(L.inv.x) < 1e30f && __builtin_fabsf(L.inv.y) < 1e30f && __builtin_fabsf(L.inv.z) < 1e30f &&
                 __builtin_fabsf(L.noi.x) < 1e30f && __builtin_fabsf(L.noi.y) < 1e30f && __builtin_fabsf(L.noi.z) < 1e30f);
-    L.h = Hit{MI_NO_HIT, 0.0f, 0.0f, -1};
+    L.h = Hit{t0, 0.0f, 0.0f, -1};
     L.sp = 0;
     L.pend0 = L.pend1 = MI_NONE;
     if (sc.n_tri + sc.n_sph == 0) {       // bvh.cu:174-176,180-181
@@ -472,7 +472,9 @@ __device__ __forceinline__ void leaf_phase(const DevScene &sc, Lane &L) { // one
 // PRIMARY = true is level 0: the stream is the identity over the batch's slots, rays
 // come from primary_ray(), and the number of slots that are real pixels is added to
 // *primary_count (it is the level-0 ray count).
-template <bool COUNT, bool PRIMARY>
+// ANY = true is the any-hit (occlusion) query: ray_d[i].w is the ray's maximum distance,
+// the lane stops at the first accepted primitive, and hits[i].y >= 0 means "occluded".
+template <bool COUNT, bool PRIMARY, bool ANY = false>
 __global__ void __launch_bounds__(MI_BLOCK)
 k_extend(DevScene sc, const uint32_t *count_ptr, uint32_t fixed_count, uint32_t segcap,
          const float4 *ray_o, const float4 *ray_d, float4 *hits, int *ovf, unsigned long long *work_stats, int refill_min,
@@ -524,6 +526,7 @@ k_extend(DevScene sc, const uint32_t *count_ptr, uint32_t fixed_count, uint32_t 
                 const uint32_t avail = rng_end - rng_next;
                 bool take = !active && rank < avail;
                 f3 o = mk3(0, 0, 0), d = mk3(0, 0, 0);
+                float t0 = MI_NO_HIT;
                 if (PRIMARY) {
                     if (take) {
                         slot = idx;
@@ -535,10 +538,12 @@ k_extend(DevScene sc, const uint32_t *count_ptr, uint32_t fixed_count, uint32_t 
                 } else if (take) {
                     slot = idx;
                     o = xyz(ray_o[idx]);
-                    d = xyz(ray_d[idx]);
+                    const float4 d4 = ray_d[idx];
+                    d = xyz(d4);
+                    if (ANY) t0 = d4.w;
                 }
                 if (take) {
-                    lane_start(sc, L, o, d);
+                    lane_start(sc, L, o, d, t0);
                     active = true;
                 }
                 rng_next += (uint32_t)n_idle < avail ? (uint32_t)n_idle : avail;
@@ -553,6 +558,7 @@ k_extend(DevScene sc, const uint32_t *count_ptr, uint32_t fixed_count, uint32_t 
             if (want_leaf) {
                 if (COUNT) n_leaves++;
                 leaf_phase(sc, L);
+                if (ANY && L.h.slot >= 0) { L.cur = MI_DONE; L.pend0 = L.pend1 = MI_NONE; } // first accepted hit ends the query
             }
         } else if (want_node) {
             if (COUNT) {
@@ -930,6 +936,12 @@ k_probe_out(DevScene sc, int64_t n, const float4 *ray_o, const float4 *ray_d, co
         }
         n_out[3 * i] = N.x; n_out[3 * i + 1] = N.y; n_out[3 * i + 2] = N.z;
     }
+}
+
+__global__ void __launch_bounds__(MI_BLOCK)
+k_probe_occluded(int64_t n, const float4 *hits, uint8_t *out) {
+    int64_t i = (int64_t)blockIdx.x * MI_BLOCK + threadIdx.x;
+    if (i < n) out[i] = __float_as_int(hits[i].y) >= 0 ? 1 : 0;
 }
 
 // Gathered shard-local RGBA8 -> bottom-up RGB8 frame (tracer.cu:96 layout).

@@ -87,7 +87,7 @@ static const int kCounterWords = (kMaxLevels + 1) * kLevelWords + MI_CNT_STRIDE;
 
 static int extend_grid(const mi_ctx *c) { return c->n_cu * c->extend_wg_per_cu; }
 
-MI_API int mi_abi_version(void) { return 3; }
+MI_API int mi_abi_version(void) { return 4; }
 MI_API const char *mi_last_error(void) { return g_err.c_str(); }
 
 MI_API mi_status mi_ctx_create(int device_id, mi_ctx **out) {
@@ -574,6 +574,38 @@ MI_API mi_status mi_trace_rays(mi_ctx *c, int64_t total, const float *rays, int3
         HIPCHK(hipMemcpyAsync(c->ray_d[0].p, d4.data(), (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
         mi_status ps = probe_chunk(c, n, prim_id_out + first, t_out + first, n_out ? n_out + 3 * first : nullptr);
         if (ps != MI_OK) return ps;
+    }
+    return MI_OK;
+}
+
+MI_API mi_status mi_occluded_rays(mi_ctx *c, int64_t total, const float *rays, const float *tmax, uint8_t *occluded_out) {
+    if (!c || !rays || !tmax || !occluded_out || total < 0) return fail(MI_ERR_INVALID, "mi_occluded_rays: bad argument");
+    if (!c->has_scene) return fail(MI_ERR_NO_SCENE, "mi_occluded_rays: no scene uploaded");
+    if (total == 0) return MI_OK;
+    HIPCHK(hipSetDevice(c->device));
+    const int64_t chunk = std::min<int64_t>(total, (int64_t)4 << 20);
+    mi_status as = probe_alloc(c, (size_t)chunk);
+    if (as != MI_OK) return as;
+    hipStream_t st = c->stream;
+    std::vector<float> o4((size_t)chunk * 4), d4((size_t)chunk * 4);
+    for (int64_t first = 0; first < total; first += chunk) {
+        const int64_t n = std::min(chunk, total - first);
+        for (int64_t i = 0; i < n; i++) {
+            const float *r = rays + 6 * (first + i);
+            o4[4 * i] = r[0]; o4[4 * i + 1] = r[1]; o4[4 * i + 2] = r[2]; o4[4 * i + 3] = 0;
+            d4[4 * i] = r[3]; d4[4 * i + 1] = r[4]; d4[4 * i + 2] = r[5]; d4[4 * i + 3] = tmax[first + i] < MI_NO_HIT ? tmax[first + i] : MI_NO_HIT; // clamp (also NaN) to the reference's "no hit yet" distance
+        }
+        HIPCHK(hipMemcpyAsync(c->ray_o[0].p, o4.data(), (size_t)n * 16, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(c->ray_d[0].p, d4.data(), (size_t)n * 16, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL((k_extend<false, false, true>), dim3(extend_grid(c)), dim3(MI_BLOCK), 0, st, c->sc, (const uint32_t *)nullptr, (uint32_t)n,
+                           0u, c->ray_o[0].as<float4>(), c->ray_d[0].as<float4>(), c->hits.as<float4>(), c->ovf.as<int>(),
+                           (unsigned long long *)nullptr, c->refill_min, c->leaf_min, ShardGeom{}, 0u, 1u, (uint32_t *)nullptr,
+                           (const uint32_t *)nullptr, 0);
+        hipLaunchKernelGGL(k_probe_occluded, dim3((unsigned)((n + MI_BLOCK - 1) / MI_BLOCK)), dim3(MI_BLOCK), 0, st, n, c->hits.as<float4>(),
+                           c->probe_i.as<uint8_t>());
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(occluded_out + first, c->probe_i.p, (size_t)n, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
     }
     return MI_OK;
 }

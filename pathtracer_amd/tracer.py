@@ -78,6 +78,16 @@ class Context:
                                    nrm.ctypes.data if want_normals else None))
         return ids, t, nrm
 
+    def occluded_rays(self, rays, tmax):
+        """Any-hit query (mi_occluded_rays): uint8[n], 1 = something is hit within tmax."""
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
+        tmax = np.ascontiguousarray(tmax, np.float32).reshape(-1)
+        if len(tmax) != len(rays):
+            raise ValueError("one tmax per ray")
+        out = np.empty(len(rays), np.uint8)
+        N.check(N.mi.mi_occluded_rays(self._h, len(rays), rays.ctypes.data, tmax.ctypes.data, out.ctypes.data))
+        return out
+
 
 def shard_pixels(params):
     return N.mi.mi_shard_pixels(C.byref(params))

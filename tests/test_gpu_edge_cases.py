@@ -116,6 +116,34 @@ def test_bounce_ray_probe_matches_brute_force(ctx, scenes_small):
         assert np.array_equal(ids, oi) and same(t, ot) and same(nrm, on)
 
 
+def test_any_hit_matches_test_of_every_primitive(ctx, scenes_small):
+    """mi_occluded_rays (no counterpart in the reference) against the oracle's any-hit
+    over every primitive; and consistent with the closest-hit probe."""
+    rng = np.random.default_rng(11)
+    for name in ("glass", "blob3", "cornell", "simple"):
+        sc = scenes_small[name]
+        ctx.upload(sc)
+        n = 20000
+        o = rng.uniform(-3, 3, (n, 3)).astype(np.float32)
+        d = rng.normal(size=(n, 3)).astype(np.float32)
+        d[:200, 0] = 0
+        d[200:400, 1] = 0
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        rays = np.concatenate([o, d], 1)
+        tmax = rng.uniform(0.0, 6.0, n).astype(np.float32)
+        tmax[:50] = 0.0
+        tmax[50:100] = -1.0
+        tmax[100:150] = np.float32(12345678.9)
+        tmax[150:200] = np.inf
+        occ = ctx.occluded_rays(rays, tmax)
+        assert np.array_equal(occ, O.occluded(sc, rays, tmax))
+        # triangles-only scenes: occluded <=> the closest hit is within tmax (t <= tmax, trimesh.cu:96)
+        if sc.soa.contents.n_sph == 0:
+            ids, t, _ = ctx.trace_rays(rays, want_normals=False)
+            assert np.array_equal(occ.astype(bool), (ids >= 0) & (t <= tmax))
+        assert 0 < occ.sum() < n
+
+
 def test_per_vertex_materials(ctx):
     txt = H + CAM + """polymesh { points = ((-2,-2,0),(2,-2,0),(2,2,0),(-2,2,0)); faces = ((0,1,2,3));
       materials = ({ diffuse = (1,0,0); emissive = (0.02,0,0); }, { diffuse = (0,1,0); reflective = (0.5,0.5,0.5); },
