@@ -138,6 +138,36 @@ void mi_ctx_destroy(mi_ctx *ctx);
  * only.  Replaces Scene::clone (scene.cu:3-13) + flatten_clone (bvh.cu:395-415). */
 mi_status mi_scene_upload(mi_ctx *ctx, const mi_scene_soa *scene);
 
+/* Same as mi_scene_upload, but the BVH is BUILT ON THE DEVICE: scene->nodes / n_nodes /
+ * root_ref are ignored, primitives stay in the caller's slot order, and tri_verts gives the
+ * three vertices of every triangle slot (float[9*n_tri], HOST; the boxes of
+ * geometry.h:13-29 need them — the precomputed uInv/vInv/nInv do not contain them).
+ * Replaces the host-side BoundedVolumeHierarchy::construct + flatten (bvh.cu:66-172,
+ * 239-369) with an LBVH: Morton codes, one radix sort, Karras topology,
+ * bottom-up fit.  The rendered image does not depend on which tree is used (exact-t ties
+ * are resolved by primitive id and child boxes are padded, see mi_scene_soa.prim_id), so
+ * renders with this tree are bit-identical to renders with an uploaded one.  A tree
+ * deeper than 64 levels is rejected (MI_ERR_INVALID).  stats may be NULL. */
+typedef struct mi_build_stats {
+    double ms_build;     /* device time of the build kernels (HIP events)               */
+    double sah_cost;     /* 1 + sum of child-box areas / root area (unit costs)          */
+    int32_t depth;       /* levels of interior nodes                                     */
+    uint32_t n_nodes;
+} mi_build_stats;
+mi_status mi_scene_upload_build(mi_ctx *ctx, const mi_scene_soa *scene, const float *tri_verts,
+                                mi_build_stats *stats);
+
+/* SAH cost (same definition as mi_build_stats.sah_cost, on the padded boxes) of the tree
+ * resident in the context, whichever way it got there.  The reference reports BVH quality
+ * only as render time (report 5.2); no counterpart. */
+mi_status mi_scene_quality(mi_ctx *ctx, double *sah_cost_out);
+
+/* Copy the resident tree back (n_nodes*16 floats in the mi_scene_soa node format), e.g.
+ * to validate or to hand a device-built tree to the CPU checker.  nodes_out == NULL only
+ * queries n_nodes / root_ref.  No counterpart in the reference. */
+mi_status mi_scene_download_nodes(mi_ctx *ctx, float *nodes_out, uint32_t capacity_nodes,
+                                  uint32_t *n_nodes_out, int32_t *root_ref_out);
+
 /* Render (this shard of) the image: the whole of GpuTracer::traceImage
  * (GpuTracer.cu:161-189) incl. the host setPixel loop (:186-188, tracer.cu:95-100).
  *   rgba_mean_out : float4[width*height] mean clamped radiance per pixel (what

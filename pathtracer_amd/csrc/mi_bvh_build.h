@@ -1,0 +1,208 @@
+// mi_bvh_build.h — BVH construction on the device.
+//
+// The reference builds its hierarchy on the host (agglomerative clustering over a
+// sorted list, src/scene/bvh.cu:66-172) and flattens it (bvh.cu:239-369); its report
+// names BVH quality as "the significant factor".  This builder is not a restatement of
+// that algorithm ("not to be replicated") — the closest hit does not depend on
+// the tree (canonical tie rule + padded boxes), so any valid tree renders
+// the same image bit for bit.  It is an LBVH (Karras 2012): 30-bit Morton codes of the
+// primitive centroids, one radix sort (hipCUB), every interior node found independently
+// from the longest common prefix of neighbouring keys, boxes fitted bottom-up, then
+// emitted in the 64-B node format of include/mi_tracer.h (both child boxes in the
+// parent).  Primitive records are not moved: leaf refs are ~slot of the caller's order.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+#include <stdint.h>
+
+#define MI_BUILD_BLOCK 256
+
+struct BuildBox {
+    float lo[3], hi[3];
+};
+
+// geometry.h:13-29 — triangle box = min/max of the three vertices, sphere box = c +- r.
+__global__ void __launch_bounds__(MI_BUILD_BLOCK)
+k_build_prim_bounds(uint32_t n_tri, uint32_t n_sph, const float *tri_verts, const float4 *sph, BuildBox *pb, float *scene_box) {
+    const uint32_t i = blockIdx.x * MI_BUILD_BLOCK + threadIdx.x;
+    const uint32_t n = n_tri + n_sph;
+    BuildBox b;
+    for (int k = 0; k < 3; k++) { b.lo[k] = 3.0e38f; b.hi[k] = -3.0e38f; }
+    if (i < n_tri) {
+        const float *v = tri_verts + 9 * (size_t)i;
+        for (int k = 0; k < 3; k++) {
+            b.lo[k] = fminf(fminf(v[k], v[3 + k]), v[6 + k]);
+            b.hi[k] = fmaxf(fmaxf(v[k], v[3 + k]), v[6 + k]);
+        }
+    } else if (i < n) {
+        const float4 cr = sph[i - n_tri];
+        const float c[3] = {cr.x, cr.y, cr.z};
+        for (int k = 0; k < 3; k++) { b.lo[k] = c[k] - cr.w; b.hi[k] = c[k] + cr.w; }
+    }
+    if (i < n) pb[i] = b;
+    // scene box: wave reduction, then one float atomic per wave and component (floats of
+    // either sign order correctly through the int/uint trick below)
+    for (int k = 0; k < 3; k++) {
+        float lo = b.lo[k], hi = b.hi[k];
+        for (int off = 32; off > 0; off >>= 1) {
+            lo = fminf(lo, __shfl_xor(lo, off));
+            hi = fmaxf(hi, __shfl_xor(hi, off));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            // atomicMin/Max on floats via ordered-int encoding
+            if (lo >= 0) atomicMin((int *)&scene_box[k], __float_as_int(lo)); else atomicMax((unsigned int *)&scene_box[k], __float_as_uint(lo));
+            if (hi >= 0) atomicMax((int *)&scene_box[3 + k], __float_as_int(hi)); else atomicMin((unsigned int *)&scene_box[3 + k], __float_as_uint(hi));
+        }
+    }
+}
+
+__device__ __forceinline__ uint32_t expand_bits10(uint32_t v) { // 10 bits -> every third bit
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+
+// key = (30-bit Morton code of the centroid) << 32 | primitive slot: unique, so the
+// common-prefix function is well defined for coincident centroids.
+__global__ void __launch_bounds__(MI_BUILD_BLOCK)
+k_build_morton(uint32_t n, const BuildBox *pb, const float *scene_box, uint64_t *keys, uint32_t *vals) {
+    const uint32_t i = blockIdx.x * MI_BUILD_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    uint32_t code = 0;
+    for (int k = 0; k < 3; k++) {
+        const float lo = scene_box[k], hi = scene_box[3 + k];
+        const float c = 0.5f * (pb[i].lo[k] + pb[i].hi[k]);
+        const float ext = hi - lo;
+        float u = ext > 0 ? (c - lo) / ext : 0.0f;
+        u = fminf(fmaxf(u * 1024.0f, 0.0f), 1023.0f);
+        code |= expand_bits10((uint32_t)u) << (2 - k);
+    }
+    keys[i] = ((uint64_t)code << 32) | i;
+    vals[i] = i;
+}
+
+// Longest common prefix of sorted keys i and j (-1 outside the array).
+__device__ __forceinline__ int build_delta(const uint64_t *keys, int n, int i, int j) {
+    if (j < 0 || j >= n) return -1;
+    return __clzll((long long)(keys[i] ^ keys[j]));
+}
+
+// Karras 2012, one thread per interior node i in [0, n-1): range, split, children.
+// child ref >= 0: interior node, < 0: ~(position in sorted order) for now.
+__global__ void __launch_bounds__(MI_BUILD_BLOCK)
+k_build_topology(int n, const uint64_t *keys, int2 *children, int *parent_node, int *parent_leaf) {
+    const int i = blockIdx.x * MI_BUILD_BLOCK + threadIdx.x;
+    if (i >= n - 1) return;
+    const int d = (build_delta(keys, n, i, i + 1) - build_delta(keys, n, i, i - 1)) >= 0 ? 1 : -1;
+    const int dmin = build_delta(keys, n, i, i - d);
+    int lmax = 2;
+    while (build_delta(keys, n, i, i + lmax * d) > dmin) lmax <<= 1;
+    int l = 0;
+    for (int t = lmax >> 1; t >= 1; t >>= 1)
+        if (build_delta(keys, n, i, i + (l + t) * d) > dmin) l += t;
+    const int j = i + l * d;
+    const int dnode = build_delta(keys, n, i, j);
+    int s = 0;
+    for (int t = (l + 1) >> 1;; t = (t + 1) >> 1) {
+        if (build_delta(keys, n, i, i + (s + t) * d) > dnode) s += t;
+        if (t <= 1) break; // (l >= 1 for unique keys; t == 0 cannot loop for ever either)
+    }
+    const int gamma = i + s * d + (d < 0 ? -1 : 0);
+    const int lo = i < j ? i : j, hi = i < j ? j : i;
+    int2 c;
+    if (lo == gamma) { c.x = ~gamma; parent_leaf[gamma] = i; } else { c.x = gamma; parent_node[gamma] = i; }
+    if (hi == gamma + 1) { c.y = ~(gamma + 1); parent_leaf[gamma + 1] = i; } else { c.y = gamma + 1; parent_node[gamma + 1] = i; }
+    children[i] = c;
+    if (i == 0) parent_node[0] = -1;
+}
+
+// Bottom-up fit: one thread per leaf climbs; the second thread to arrive at a node owns
+// it (both children are complete), the first one leaves.  Every thread terminates: it
+// either leaves at a flag or reaches the root.
+__device__ __forceinline__ BuildBox build_load_box(const BuildBox *p) { // written by another thread of this launch
+    const volatile float *f = (const volatile float *)p;
+    BuildBox b;
+    for (int k = 0; k < 3; k++) { b.lo[k] = f[k]; b.hi[k] = f[3 + k]; }
+    return b;
+}
+__global__ void __launch_bounds__(MI_BUILD_BLOCK)
+k_build_fit(int n, const uint32_t *sorted_slot, const BuildBox *pb, const int2 *children, const int *parent_node,
+            const int *parent_leaf, BuildBox *nb, int *height, unsigned int *flags) {
+    const int leaf = blockIdx.x * MI_BUILD_BLOCK + threadIdx.x;
+    if (leaf >= n) return;
+    int cur = parent_leaf[leaf];
+    while (cur >= 0) {
+        __threadfence(); // my child's box and height are visible before the flag is raised
+        if (atomicAdd(&flags[cur], 1u) == 0u) return;
+        __threadfence(); // the sibling's box and height are visible after the flag is seen
+        const int2 c = children[cur];
+        BuildBox bl, br;
+        int hl = 0, hr = 0;
+        if (c.x < 0) bl = pb[sorted_slot[~c.x]]; else { bl = build_load_box(&nb[c.x]); hl = *(volatile int *)&height[c.x]; }
+        if (c.y < 0) br = pb[sorted_slot[~c.y]]; else { br = build_load_box(&nb[c.y]); hr = *(volatile int *)&height[c.y]; }
+        BuildBox b;
+        for (int k = 0; k < 3; k++) { b.lo[k] = fminf(bl.lo[k], br.lo[k]); b.hi[k] = fmaxf(bl.hi[k], br.hi[k]); }
+        nb[cur] = b;
+        height[cur] = 1 + (hl > hr ? hl : hr);
+        cur = parent_node[cur];
+    }
+}
+
+__device__ __forceinline__ float build_area(const BuildBox &b) {
+    const float dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
+    return 2.0f * (dx * dy + dy * dz + dz * dx);
+}
+
+// Emit the 64-B nodes of include/mi_tracer.h: padded child boxes, child refs with leaves
+// as ~slot.  Also sums the surface areas of all child boxes (SAH cost numerator).
+__global__ void __launch_bounds__(MI_BUILD_BLOCK)
+k_build_emit(int n, const uint32_t *sorted_slot, const BuildBox *pb, const int2 *children, const BuildBox *nb, float pad,
+             float4 *nodes, double *area_sum) {
+    const int i = blockIdx.x * MI_BUILD_BLOCK + threadIdx.x;
+    float area = 0.0f;
+    if (i < n - 1) {
+        const int2 c = children[i];
+        const BuildBox bl = c.x < 0 ? pb[sorted_slot[~c.x]] : nb[c.x];
+        const BuildBox br = c.y < 0 ? pb[sorted_slot[~c.y]] : nb[c.y];
+        const int rl = c.x < 0 ? ~(int)sorted_slot[~c.x] : c.x;
+        const int rr = c.y < 0 ? ~(int)sorted_slot[~c.y] : c.y;
+        nodes[4 * (size_t)i + 0] = make_float4(bl.lo[0] - pad, bl.lo[1] - pad, bl.lo[2] - pad, bl.hi[0] + pad);
+        nodes[4 * (size_t)i + 1] = make_float4(bl.hi[1] + pad, bl.hi[2] + pad, br.lo[0] - pad, br.lo[1] - pad);
+        nodes[4 * (size_t)i + 2] = make_float4(br.lo[2] - pad, br.hi[0] + pad, br.hi[1] + pad, br.hi[2] + pad);
+        nodes[4 * (size_t)i + 3] = make_float4(__int_as_float(rl), __int_as_float(rr), 0.0f, 0.0f);
+        area = build_area(bl) + build_area(br);
+    }
+    // block reduction -> one double atomic per workgroup
+    __shared__ float part[MI_BUILD_BLOCK / 64];
+    for (int off = 32; off > 0; off >>= 1) area += __shfl_xor(area, off);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = area;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0;
+        for (int w = 0; w < MI_BUILD_BLOCK / 64; w++) s += part[w];
+        if (s != 0) atomicAdd(area_sum, s);
+    }
+}
+
+// Surface-area sum of the child boxes of resident nodes (any tree, e.g. the host SAH one).
+__global__ void __launch_bounds__(MI_BUILD_BLOCK)
+k_nodes_area(uint32_t n_nodes, const float4 *nodes, double *area_sum) {
+    const uint32_t i = blockIdx.x * MI_BUILD_BLOCK + threadIdx.x;
+    float area = 0.0f;
+    if (i < n_nodes) {
+        const float4 a = nodes[4 * (size_t)i], b = nodes[4 * (size_t)i + 1], c = nodes[4 * (size_t)i + 2];
+        const BuildBox bl{{a.x, a.y, a.z}, {a.w, b.x, b.y}}, br{{b.z, b.w, c.x}, {c.y, c.z, c.w}};
+        area = build_area(bl) + build_area(br);
+    }
+    __shared__ float part[MI_BUILD_BLOCK / 64];
+    for (int off = 32; off > 0; off >>= 1) area += __shfl_xor(area, off);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = area;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0;
+        for (int w = 0; w < MI_BUILD_BLOCK / 64; w++) s += part[w];
+        if (s != 0) atomicAdd(area_sum, s);
+    }
+}

@@ -2,6 +2,7 @@
 // render loop.  Every hip* call is checked; errors are returned as status codes
 // with a thread-local message (the reference checks nothing, GpuTracer.cu:161-189).
 #include "mi_kernels.h"
+#include "mi_bvh_build.h"
 
 #include <algorithm>
 #include <cstdarg>
@@ -87,7 +88,7 @@ static const int kCounterWords = (kMaxLevels + 1) * kLevelWords + MI_CNT_STRIDE;
 
 static int extend_grid(const mi_ctx *c) { return c->n_cu * c->extend_wg_per_cu; }
 
-MI_API int mi_abi_version(void) { return 4; }
+MI_API int mi_abi_version(void) { return 5; }
 MI_API const char *mi_last_error(void) { return g_err.c_str(); }
 
 MI_API mi_status mi_ctx_create(int device_id, mi_ctx **out) {
@@ -146,7 +147,7 @@ MI_API void mi_ctx_destroy(mi_ctx *c) {
 
 // Host-side validation of the flattened BVH before any kernel may walk it: refs in
 // range, every primitive slot referenced exactly once, depth <= MI_MAX_STACK.
-static mi_status validate_scene(const mi_scene_soa *s) {
+static mi_status validate_prims(const mi_scene_soa *s) {
     const uint64_t n_prim = (uint64_t)s->n_tri + s->n_sph;
     if (n_prim == 0) return MI_OK;
     if (!s->prim_id || !s->materials || s->n_mat == 0) return fail(MI_ERR_INVALID, "scene: prim_id/materials missing");
@@ -158,7 +159,15 @@ static mi_status validate_scene(const mi_scene_soa *s) {
     for (uint32_t i = 0; i < s->n_sph; i++)
         if (s->sph_mat[i] >= s->n_mat) return fail(MI_ERR_INVALID, "scene: sphere material id out of range");
     // node and triangle records are addressed with 32-bit byte offsets (64 B each)
-    if (s->n_nodes >= (1u << 26) || s->n_tri >= (1u << 26)) return fail(MI_ERR_INVALID, "scene: more than 2^26 nodes or triangles");
+    if (n_prim >= (1u << 26)) return fail(MI_ERR_INVALID, "scene: more than 2^26 primitives");
+    return MI_OK;
+}
+
+static mi_status validate_scene(const mi_scene_soa *s) {
+    const uint64_t n_prim = (uint64_t)s->n_tri + s->n_sph;
+    mi_status ps = validate_prims(s);
+    if (ps != MI_OK || n_prim == 0) return ps;
+    if (s->n_nodes >= (1u << 26)) return fail(MI_ERR_INVALID, "scene: more than 2^26 nodes");
     if (n_prim == 1) {
         if (s->root_ref != ~0) return fail(MI_ERR_INVALID, "scene: one primitive needs root_ref == ~0");
         return MI_OK;
@@ -194,19 +203,14 @@ static mi_status validate_scene(const mi_scene_soa *s) {
     return MI_OK;
 }
 
-MI_API mi_status mi_scene_upload(mi_ctx *c, const mi_scene_soa *s) {
-    if (!c || !s) return fail(MI_ERR_INVALID, "mi_scene_upload: NULL argument");
-    c->has_scene = false; // a rejected or failed upload leaves the context without a scene
-    mi_status vs = validate_scene(s);
-    if (vs != MI_OK) return vs;
-    HIPCHK(hipSetDevice(c->device));
+// Copies primitives, materials, ids and camera (everything but the nodes) to the device.
+static mi_status upload_prims(mi_ctx *c, const mi_scene_soa *s) {
     const size_t nt = s->n_tri, ns = s->n_sph;
     auto up = [&](DevBuf &b, const void *src, size_t bytes) -> hipError_t {
         hipError_t e = b.ensure(std::max<size_t>(bytes, 16));
         if (e != hipSuccess || bytes == 0) return e;
         return hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice);
     };
-    HIPCHK(up(c->nodes, s->nodes, (size_t)s->n_nodes * 64));
     // interleave v0,uInv,vInv,nInv into one 64-B record per triangle
     std::vector<float> rec(16 * nt);
     for (size_t i = 0; i < nt; i++) {
@@ -224,7 +228,6 @@ MI_API mi_status mi_scene_upload(mi_ctx *c, const mi_scene_soa *s) {
     HIPCHK(up(c->mats, s->materials, (size_t)s->n_mat * 80));
     HIPCHK(up(c->prim_id, s->prim_id, (nt + ns) * 4));
     DevScene &d = c->sc;
-    d.nodes = c->nodes.as<float4>();
     d.tri = c->tri.as<float4>();
     d.tri_normal = c->tri_normal.as<float4>();
     d.tri_mat = c->tri_mat.as<uint32_t>();
@@ -233,14 +236,180 @@ MI_API mi_status mi_scene_upload(mi_ctx *c, const mi_scene_soa *s) {
     d.sph_mat = c->sph_mat.as<uint32_t>();
     d.mats = c->mats.as<float4>();
     d.prim_id = c->prim_id.as<int32_t>();
-    d.root_ref = s->root_ref;
     d.n_tri = s->n_tri;
     d.n_sph = s->n_sph;
     d.eye = make_float4(s->cam_eye[0], s->cam_eye[1], s->cam_eye[2], s->cam_eye[3]);
     d.u = make_float4(s->cam_u[0], s->cam_u[1], s->cam_u[2], s->cam_u[3]);
     d.v = make_float4(s->cam_v[0], s->cam_v[1], s->cam_v[2], s->cam_v[3]);
     d.look = make_float4(s->cam_look[0], s->cam_look[1], s->cam_look[2], s->cam_look[3]);
+    return MI_OK;
+}
+
+MI_API mi_status mi_scene_upload(mi_ctx *c, const mi_scene_soa *s) {
+    if (!c || !s) return fail(MI_ERR_INVALID, "mi_scene_upload: NULL argument");
+    c->has_scene = false; // a rejected or failed upload leaves the context without a scene
+    mi_status vs = validate_scene(s);
+    if (vs != MI_OK) return vs;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(c->nodes.ensure(std::max<size_t>((size_t)s->n_nodes * 64, 16)));
+    if (s->n_nodes) HIPCHK(hipMemcpy(c->nodes.p, s->nodes, (size_t)s->n_nodes * 64, hipMemcpyHostToDevice));
+    mi_status us = upload_prims(c, s);
+    if (us != MI_OK) return us;
+    c->sc.nodes = c->nodes.as<float4>();
+    c->sc.root_ref = s->root_ref;
     c->n_nodes = s->n_nodes;
+    c->has_scene = true;
+    return MI_OK;
+}
+
+// Sum of the surface areas of all child boxes of the resident tree / area of the root's
+// box, + 1 for the root: the SAH cost with unit node and leaf costs.
+static mi_status resident_sah_cost(mi_ctx *c, double *out) {
+    *out = 0.0;
+    if (c->n_nodes == 0) return MI_OK;
+    DevBuf acc;
+    HIPCHK(acc.ensure(8));
+    HIPCHK(hipMemsetAsync(acc.p, 0, 8, c->stream));
+    hipLaunchKernelGGL(k_nodes_area, dim3((c->n_nodes + MI_BUILD_BLOCK - 1) / MI_BUILD_BLOCK), dim3(MI_BUILD_BLOCK), 0, c->stream, c->n_nodes,
+                       c->nodes.as<float4>(), acc.as<double>());
+    double sum = 0;
+    float root[16];
+    hipError_t e = hipMemcpyAsync(&sum, acc.p, 8, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(root, (const char *)c->nodes.p + (size_t)c->sc.root_ref * 64, 64, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    acc.release();
+    HIPCHK(e);
+    float lo[3], hi[3];
+    for (int k = 0; k < 3; k++) { lo[k] = std::min(root[k], root[6 + k]); hi[k] = std::max(root[3 + k], root[9 + k]); }
+    const double dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+    const double a = 2.0 * (dx * dy + dy * dz + dz * dx);
+    *out = a > 0 ? 1.0 + sum / a : 0.0;
+    return MI_OK;
+}
+
+MI_API mi_status mi_scene_quality(mi_ctx *c, double *sah_cost_out) {
+    if (!c || !sah_cost_out) return fail(MI_ERR_INVALID, "mi_scene_quality: NULL argument");
+    if (!c->has_scene) return fail(MI_ERR_NO_SCENE, "mi_scene_quality: no scene uploaded");
+    HIPCHK(hipSetDevice(c->device));
+    return resident_sah_cost(c, sah_cost_out);
+}
+
+MI_API mi_status mi_scene_download_nodes(mi_ctx *c, float *nodes_out, uint32_t capacity_nodes, uint32_t *n_nodes_out, int32_t *root_ref_out) {
+    if (!c || !n_nodes_out || !root_ref_out) return fail(MI_ERR_INVALID, "mi_scene_download_nodes: NULL argument");
+    if (!c->has_scene) return fail(MI_ERR_NO_SCENE, "mi_scene_download_nodes: no scene uploaded");
+    *n_nodes_out = c->n_nodes;
+    *root_ref_out = c->sc.root_ref;
+    if (!nodes_out) return MI_OK; // size query
+    if (capacity_nodes < c->n_nodes) return fail(MI_ERR_INVALID, "mi_scene_download_nodes: room for %u nodes, tree has %u", capacity_nodes, c->n_nodes);
+    HIPCHK(hipSetDevice(c->device));
+    if (c->n_nodes) HIPCHK(hipMemcpy(nodes_out, c->nodes.p, (size_t)c->n_nodes * 64, hipMemcpyDeviceToHost));
+    return MI_OK;
+}
+
+MI_API mi_status mi_scene_upload_build(mi_ctx *c, const mi_scene_soa *s, const float *tri_verts, mi_build_stats *stats) {
+    if (!c || !s) return fail(MI_ERR_INVALID, "mi_scene_upload_build: NULL argument");
+    c->has_scene = false;
+    if (stats) memset(stats, 0, sizeof *stats);
+    mi_status vs = validate_prims(s);
+    if (vs != MI_OK) return vs;
+    if (s->n_tri && !tri_verts) return fail(MI_ERR_INVALID, "mi_scene_upload_build: tri_verts is NULL");
+    const uint32_t n = s->n_tri + s->n_sph;
+    for (size_t i = 0; i < 9 * (size_t)s->n_tri; i++)
+        if (!(tri_verts[i] > -1e15f && tri_verts[i] < 1e15f)) return fail(MI_ERR_INVALID, "scene: non-finite or huge vertex");
+    for (size_t i = 0; i < 4 * (size_t)s->n_sph; i++)
+        if (!(s->sph_center_radius[i] > -1e15f && s->sph_center_radius[i] < 1e15f)) return fail(MI_ERR_INVALID, "scene: non-finite or huge sphere");
+    HIPCHK(hipSetDevice(c->device));
+    mi_status us = upload_prims(c, s);
+    if (us != MI_OK) return us;
+    c->sc.nodes = nullptr;
+    c->n_nodes = 0;
+    if (n <= 1) { // no interior node: bvh.cu:174-183
+        HIPCHK(c->nodes.ensure(16));
+        c->sc.nodes = c->nodes.as<float4>();
+        c->sc.root_ref = ~0;
+        c->has_scene = true;
+        return MI_OK;
+    }
+    hipStream_t st = c->stream;
+    // build-time scratch, released when the build is done (the build is not a hot path)
+    DevBuf verts, pb, sbox, keys_a, keys_b, vals_a, vals_b, children, par_n, par_l, nb, height, flags, area, cub_tmp;
+    DevBuf *tmp[] = {&verts, &pb, &sbox, &keys_a, &keys_b, &vals_a, &vals_b, &children, &par_n, &par_l, &nb, &height, &flags, &area, &cub_tmp};
+    mi_status rs = MI_OK;
+    auto body = [&]() -> mi_status {
+        HIPCHK(verts.ensure(std::max<size_t>((size_t)s->n_tri * 36, 16)));
+        if (s->n_tri) HIPCHK(hipMemcpyAsync(verts.p, tri_verts, (size_t)s->n_tri * 36, hipMemcpyHostToDevice, st));
+        HIPCHK(pb.ensure((size_t)n * sizeof(BuildBox)));
+        HIPCHK(sbox.ensure(32));
+        HIPCHK(keys_a.ensure((size_t)n * 8));
+        HIPCHK(keys_b.ensure((size_t)n * 8));
+        HIPCHK(vals_a.ensure((size_t)n * 4));
+        HIPCHK(vals_b.ensure((size_t)n * 4));
+        HIPCHK(children.ensure((size_t)n * 8));
+        HIPCHK(par_n.ensure((size_t)n * 4));
+        HIPCHK(par_l.ensure((size_t)n * 4));
+        HIPCHK(nb.ensure((size_t)n * sizeof(BuildBox)));
+        HIPCHK(height.ensure((size_t)n * 4));
+        HIPCHK(flags.ensure((size_t)n * 4));
+        HIPCHK(area.ensure(8));
+        HIPCHK(c->nodes.ensure((size_t)(n - 1) * 64));
+        size_t cub_bytes = 0;
+        HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, cub_bytes, keys_a.as<uint64_t>(), keys_b.as<uint64_t>(), vals_a.as<uint32_t>(),
+                                                  vals_b.as<uint32_t>(), (int)n, 0, 62, st));
+        HIPCHK(cub_tmp.ensure(std::max<size_t>(cub_bytes, 16)));
+        hipEvent_t e0, e1;
+        HIPCHK(hipEventCreate(&e0));
+        HIPCHK(hipEventCreate(&e1));
+        const float init_box[8] = {3.0e38f, 3.0e38f, 3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f, 0, 0};
+        HIPCHK(hipMemcpyAsync(sbox.p, init_box, 32, hipMemcpyHostToDevice, st));
+        HIPCHK(hipStreamSynchronize(st)); // host sources above are stack/borrowed memory
+        HIPCHK(hipEventRecord(e0, st));
+        const dim3 grid((n + MI_BUILD_BLOCK - 1) / MI_BUILD_BLOCK), block(MI_BUILD_BLOCK);
+        HIPCHK(hipMemsetAsync(flags.p, 0, (size_t)n * 4, st));
+        HIPCHK(hipMemsetAsync(height.p, 0, (size_t)n * 4, st));
+        HIPCHK(hipMemsetAsync(area.p, 0, 8, st));
+        hipLaunchKernelGGL(k_build_prim_bounds, grid, block, 0, st, s->n_tri, s->n_sph, verts.as<float>(), c->sph.as<float4>(), pb.as<BuildBox>(),
+                           sbox.as<float>());
+        hipLaunchKernelGGL(k_build_morton, grid, block, 0, st, n, pb.as<BuildBox>(), sbox.as<float>(), keys_a.as<uint64_t>(), vals_a.as<uint32_t>());
+        HIPCHK(hipcub::DeviceRadixSort::SortPairs(cub_tmp.p, cub_bytes, keys_a.as<uint64_t>(), keys_b.as<uint64_t>(), vals_a.as<uint32_t>(),
+                                                  vals_b.as<uint32_t>(), (int)n, 0, 62, st));
+        hipLaunchKernelGGL(k_build_topology, grid, block, 0, st, (int)n, keys_b.as<uint64_t>(), children.as<int2>(), par_n.as<int>(), par_l.as<int>());
+        hipLaunchKernelGGL(k_build_fit, grid, block, 0, st, (int)n, vals_b.as<uint32_t>(), pb.as<BuildBox>(), children.as<int2>(), par_n.as<int>(),
+                           par_l.as<int>(), nb.as<BuildBox>(), height.as<int>(), flags.as<unsigned int>());
+        // padding needs the scene diagonal: one small read-back in the middle of the build
+        float hb[8];
+        HIPCHK(hipMemcpyAsync(hb, sbox.p, 32, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        const double dx = (double)hb[3] - hb[0], dy = (double)hb[4] - hb[1], dz = (double)hb[5] - hb[2];
+        const float pad = 1e-5f * (float)std::sqrt(dx * dx + dy * dy + dz * dz) + 1e-30f; // as the host flattener
+        hipLaunchKernelGGL(k_build_emit, grid, block, 0, st, (int)n, vals_b.as<uint32_t>(), pb.as<BuildBox>(), children.as<int2>(), nb.as<BuildBox>(), pad,
+                           c->nodes.as<float4>(), area.as<double>());
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(e1, st));
+        int h_root = 0;
+        double area_sum = 0;
+        HIPCHK(hipMemcpyAsync(&h_root, height.p, 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(&area_sum, area.p, 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        if (h_root > MI_MAX_STACK) return fail(MI_ERR_INVALID, "device-built BVH is %d levels deep (limit %d)", h_root, MI_MAX_STACK);
+        if (stats) {
+            const double a = 2.0 * (dx * dy + dy * dz + dz * dx);
+            stats->ms_build = ms;
+            stats->sah_cost = a > 0 ? 1.0 + area_sum / a : 0.0;
+            stats->depth = h_root;
+            stats->n_nodes = n - 1;
+        }
+        return MI_OK;
+    };
+    rs = body();
+    for (DevBuf *b : tmp) b->release();
+    if (rs != MI_OK) return rs;
+    c->sc.nodes = c->nodes.as<float4>();
+    c->sc.root_ref = 0; // Karras: interior node 0 is the root
+    c->n_nodes = n - 1;
     c->has_scene = true;
     return MI_OK;
 }

@@ -33,6 +33,27 @@ class Context:
         N.check(N.mi.mi_scene_upload(self._h, scene.soa))
         self.scene = scene  # keep the host arrays alive (not required by the ABI)
 
+    def upload_build(self, scene: Scene):
+        """Upload the primitives and build the BVH on the device (mi_scene_upload_build)."""
+        verts = np.ascontiguousarray(scene.slot_vertices()[:, :, :3], np.float32)
+        st = N.BuildStats()
+        N.check(N.mi.mi_scene_upload_build(self._h, scene.soa, verts.ctypes.data if len(verts) else None, C.byref(st)))
+        self.scene = scene
+        return st
+
+    def scene_quality(self):
+        v = C.c_double()
+        N.check(N.mi.mi_scene_quality(self._h, C.byref(v)))
+        return v.value
+
+    def download_nodes(self):
+        """(float32[n_nodes,16] nodes, root_ref) of the tree resident on the device."""
+        n, root = C.c_uint32(), C.c_int32()
+        N.check(N.mi.mi_scene_download_nodes(self._h, None, 0, C.byref(n), C.byref(root)))
+        nodes = np.zeros((n.value, 16), np.float32)
+        N.check(N.mi.mi_scene_download_nodes(self._h, nodes.ctypes.data if n.value else None, n.value, C.byref(n), C.byref(root)))
+        return nodes, root.value
+
     @staticmethod
     def params(width, height, samples, depth, seed=0, tile=(0, 0), shard=(0, 1), batch_paths=0, count_work=False):
         return N.RenderParams(width, height, samples, depth, seed, tile[0], tile[1], shard[0], shard[1], batch_paths,
