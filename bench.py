@@ -37,6 +37,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="C3-blob82k-1080p-16spp", choices=sorted(WORKLOADS))
+    ap.add_argument("--bvh", default="host", choices=["host", "device"],
+                    help="host: binned-SAH tree built by libpt_host (default); device: LBVH built by mi_scene_upload_build")
     ap.add_argument("--batch-paths", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -62,7 +64,10 @@ def main():
     scene = build(S)
     w, h = scene.image_size(width)
     ctx = P.Context(local_rank)
-    ctx.upload(scene)  # scene resident in HBM before any timed region
+    build = ctx.upload_build(scene) if args.bvh == "device" else None  # scene resident in HBM before any timed region
+    if build is None:
+        ctx.upload(scene)
+    sah_cost = ctx.scene_quality()
 
     params = P.Context.params(w, h, samples, depth, seed=0, shard=(rank, world), batch_paths=args.batch_paths)
     p0 = P.Context.params(w, h, samples, depth, seed=0, shard=(0, world))
@@ -143,7 +148,9 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": args.workload, "image": [w, h], "samples_per_dim": samples, "depth": depth,
-                       "primitives": scene.n_prims, "bvh_depth": scene.bvh_depth, "sharding": f"tile32x{world}",
+                       "primitives": scene.n_prims,
+                       "bvh": "device LBVH" if build else "host binned SAH", "bvh_depth": build.depth if build else scene.bvh_depth,
+                       "bvh_sah_cost": sah_cost, "bvh_build_ms": build.ms_build if build else None, "sharding": f"tile32x{world}",
                        "rays_per_step": rays_all / args.steps},
             "roofline": {"bound": "hbm", "kernel": "k_extend", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": pmc_traffic(args.workload, world),

@@ -4,7 +4,7 @@
 // the GPU backend in the reference and is implied here (the only backend), -q
 // (CUDA threads per block) is accepted and ignored, -j/-c are accepted and
 // ignored (JSON overrides and cubemaps are outside this backend's scope).
-// Added: -G <device>, -S <seed>.
+// Added: -G <device>, -S <seed>, -B (build the BVH on the GPU).
 #include <unistd.h>
 
 #include <cmath>
@@ -17,7 +17,7 @@ int main(int argc, char **argv) {
     pt::TraceOptions o;
     int size = 512; // TraceUI.h:55
     int c;
-    while ((c = getopt(argc, argv, "t:r:w:hj:c:s:gq:G:S:")) != -1) {
+    while ((c = getopt(argc, argv, "t:r:w:hj:c:s:gq:G:S:B")) != -1) {
         switch (c) {
             case 't': o.threads = atoi(optarg); // falls through into -r, CommandLineUI.cu:29-33
             case 'r': o.depth = atoi(optarg); break;
@@ -25,11 +25,12 @@ int main(int argc, char **argv) {
             case 's': o.samples = atoi(optarg); break;
             case 'G': o.device = atoi(optarg); break;
             case 'S': o.seed = strtoull(optarg, nullptr, 10); break;
+            case 'B': o.device_bvh = true; break;
             case 'j': case 'c': case 'q': case 'g': break;
             default:
                 std::cerr << "usage: " << argv[0] << " [options] [input.ray output.png]\n"
                           << "  -r <#>  recursion level (default 0)\n  -w <#>  image width (default 512)\n"
-                          << "  -s <#>  samples per dimension (default 2)\n  -G <#>  HIP device\n  -S <#>  RNG seed\n";
+                          << "  -s <#>  samples per dimension (default 2)\n  -G <#>  HIP device\n  -S <#>  RNG seed\n  -B      build the BVH on the GPU (LBVH)\n";
                 return 1;
         }
     }

@@ -69,7 +69,17 @@ HipTracer::~HipTracer() {
 
 bool HipTracer::sceneLoaded() { // upload replaces Scene::clone, GpuTracer.cu:172-175
     if (!ctx_) return false;
-    status_ = mi_scene_upload(ctx_, &scene->soa());
+    if (opts_.device_bvh) { // slot vertices are kept as 3 float4 per triangle; the ABI takes 9 floats
+        const std::vector<float> &v4 = scene->slotVertices();
+        std::vector<float> v3(v4.size() / 12 * 9);
+        for (size_t t = 0; t < v4.size() / 12; t++)
+            for (int k = 0; k < 3; k++)
+                for (int a = 0; a < 3; a++) v3[9 * t + 3 * k + a] = v4[12 * t + 4 * k + a];
+        mi_build_stats bs;
+        status_ = mi_scene_upload_build(ctx_, &scene->soa(), v3.empty() ? nullptr : v3.data(), &bs);
+    } else {
+        status_ = mi_scene_upload(ctx_, &scene->soa());
+    }
     if (status_ != MI_OK) {
         error_ = mi_last_error();
         std::cerr << "HipTracer: " << error_ << std::endl;

@@ -23,6 +23,7 @@ struct TraceOptions {
     int threads = 0;        // -t (CPU backends only)
     int device = 0;         // HIP device of the MI355X backend
     unsigned long long seed = 0;
+    bool device_bvh = false; // build the BVH on the GPU (mi_scene_upload_build) instead of uploading the host-built one
 };
 
 class Tracer {

@@ -267,3 +267,8 @@ def test_cli_renders_a_png(tmp_path, scenes_small):
     sc = scenes_small["simple"]
     want = O.render(sc, P.Context.params(64, 65, 2, 2, seed=3))[1]
     assert img.shape == (65, 64, 3) and np.array_equal(img[::-1], want)     # PNG rows are flipped
+    # -B: BVH built on the GPU; the image is the same, byte for byte
+    out2 = tmp_path / "s2.png"
+    r = subprocess.run([exe, "-B", "-r", "2", "-w", "64", "-s", "2", "-S", "3", str(ray), str(out2)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert np.array_equal(np.array(Image.open(out2)), img)
