@@ -232,6 +232,22 @@ mi_status mi_trace_rays(mi_ctx *ctx, int64_t n, const float *rays,
 mi_status mi_occluded_rays(mi_ctx *ctx, int64_t n, const float *rays, const float *tmax,
                            uint8_t *occluded_out);
 
+/* Cubemap background: the colour of a ray that hits nothing (CpuTracer.cu:125,
+ * `cubeMap ? cubeMap->getColor(r) : 1`; CubeMap::getColor cubeMap.cu:6-31 with
+ * TextureMap::getMappedValue / getPixelAt, material.cu:20-37: major-axis face, bilinear
+ * fetch, texel / 256, clamp to edge).  CPU-only in the reference; on the device here
+ * (SURVEY 8 f4).  Faces in the order of TraceUI.cu:76-83 (+x, -x, +y, -y, +z, -z), tightly
+ * packed RGB8, row 0 = BOTTOM row of the image file (what readImage returns,
+ * pngimage.cu:210-213, bitmap.cu:70-93).  HOST pointers, copied.  The cubemap belongs to
+ * the context, not to the scene (the reference's UI owns it, TraceUI.h:78): it stays until
+ * replaced; cm == NULL removes it (white background again). */
+typedef struct mi_cubemap {
+    int32_t width[6];
+    int32_t height[6];
+    const uint8_t *rgb[6];
+} mi_cubemap;
+mi_status mi_cubemap_upload(mi_ctx *ctx, const mi_cubemap *cm);
+
 /* Thread-local description of the last error returned on this thread. */
 const char *mi_last_error(void);
 

@@ -344,6 +344,52 @@ static f4 random_vec_from_hemisphere(const f4 &normal, float u1, float u2, int s
     return sin_t * cos_p * a + sin_t * sin_p * b + cos_t * normal; /* :52 */
 }
 
+/* ------------------------------------------- cubeMap.cu:6-31, material.cu:20-37
+ * Background of rays that miss everything when a cubemap is loaded (-c, CpuTracer.cu:125).
+ * Faces in the order of TraceUI.cu:76-83: +x, -x, +y, -y, +z, -z; each is RGB8, row 0 =
+ * bottom row of the image file (pngimage.cu:210-213, bitmap.cu).  Set with orc_set_cubemap
+ * (test infrastructure: one process-wide cubemap, as the reference's TraceUI holds one). */
+struct CubeFace {
+    int width = 0, height = 0;
+    std::vector<uint8_t> data;
+};
+static CubeFace g_cube[6];
+static bool g_cube_set = false;
+
+static f4 tex_pixel_at(const CubeFace &t, int x, int y) {   /* material.cu:32-37 */
+    x = std::max(0, std::min(t.width - 1, x));
+    y = std::max(0, std::min(t.height - 1, y));
+    size_t idx = ((size_t)x + (size_t)y * t.width) * 3;
+    return f4(t.data[idx] / 256.0f, t.data[idx + 1] / 256.0f, t.data[idx + 2] / 256.0f);
+}
+static f4 tex_mapped_value(const CubeFace &t, float u, float v) { /* material.cu:20-30 */
+    float x = u * t.width;
+    float y = v * t.height;
+    float lerp_x = x - (int)x;
+    float lerp_y = y - (int)y;
+    f4 vlerp_xl = lerp_x * tex_pixel_at(t, (int)x + 1, (int)y) + (1 - lerp_x) * tex_pixel_at(t, (int)x, (int)y);
+    f4 vlerp_xr = lerp_x * tex_pixel_at(t, (int)x + 1, (int)y + 1) + (1 - lerp_x) * tex_pixel_at(t, (int)x, (int)y + 1);
+    return lerp_y * vlerp_xr + (1 - lerp_y) * vlerp_xl;
+}
+static f4 cubemap_color(const f4 &raydir, int *face_out = nullptr, float *uv_out = nullptr) { /* cubeMap.cu:6-31 */
+    f4 dir = normalize(raydir);                                            /* :10 */
+    int idx = 2;                                                           /* :11-15 */
+    if (std::abs(dir[1]) > std::abs(dir[2])) idx = 1;
+    if (std::abs(dir[0]) > std::abs(dir[2]) && std::abs(dir[0]) > std::abs(dir[1])) idx = 0;
+    int sgn = dir[idx] < 0 ? -1 : 1;                                       /* int arithmetic: unselected axes are +0 */
+    f4 forward((float)(sgn * (idx == 0)), (float)(sgn * (idx == 1)), (float)(sgn * (idx == 2))); /* :17-19 (glm::vec3 -> f4, w = 0) */
+    float dn = dot(dir, forward);
+    dir = dir / dn;                                                        /* :20 */
+    idx *= 2;                                                              /* :23-25 */
+    if ((dir[idx / 2] < 0) != (idx == 4)) idx++;
+    f4 up = idx / 2 == 1 ? f4(0, 0, (dir[idx / 2] < 0 ? -1 : 1)) : f4(0, 1, 0); /* :27 */
+    f4 right = normalize(cross(forward, up));                              /* :28 */
+    float u = 0.5f + dot(dir, right) / 2.0f, v = 0.5f + dot(dir, up) / 2.0f; /* :29 */
+    if (face_out) *face_out = idx;
+    if (uv_out) { uv_out[0] = u; uv_out[1] = v; }
+    return tex_mapped_value(g_cube[idx], u, v);                            /* :30 */
+}
+
 struct TraceCfg {
     SceneView sc;
     uint64_t seed;
@@ -363,7 +409,7 @@ static f4 trace_ray(const TraceCfg &cfg, Ray &r, const f4 &thresh, int depth, ui
     if ((double)length2(thresh) < 3.0 * 12.0 / 255.0 / 255.0)             /* :121 */
         return f4(0.0f);
     if (!scene_intersect(cfg, r, i, c))                                    /* :124 */
-        return f4(1.0f);                                                   /* :125, no cubemap */
+        return g_cube_set ? cubemap_color(r.dir) : f4(1.0f);               /* :125 */
     f4 hitInner = r.pos + (i.t + RAY_EPSILON) * r.dir;                     /* :127 */
     f4 hitOuter = r.pos + (i.t - RAY_EPSILON) * r.dir;                     /* :128 */
     if (depth < 0)                                                         /* :130 */
@@ -506,6 +552,28 @@ ORC_API int orc_trace_rays(const mi_scene_soa *s, int64_t n, const float *rays, 
         if (n_out) { n_out[3 * k] = is.N[0]; n_out[3 * k + 1] = is.N[1]; n_out[3 * k + 2] = is.N[2]; }
     }
     if (cnt) { cnt->rays = c.rays; cnt->node_visits = c.node_visits; cnt->leaf_tests = c.leaf_tests; cnt->ms = 0; }
+    return 0;
+}
+
+/* Cubemap of the following orc_render calls: faces +x,-x,+y,-y,+z,-z, RGB8, row 0 = bottom
+ * row; data == NULL clears it (white background, CpuTracer.cu:125). */
+ORC_API int orc_set_cubemap(const uint8_t *const *data, const int *width, const int *height) {
+    g_cube_set = false;
+    if (!data) return 0;
+    for (int f = 0; f < 6; f++) {
+        if (!data[f] || width[f] <= 0 || height[f] <= 0) return 1;
+        g_cube[f].width = width[f];
+        g_cube[f].height = height[f];
+        g_cube[f].data.assign(data[f], data[f] + (size_t)width[f] * height[f] * 3);
+    }
+    g_cube_set = true;
+    return 0;
+}
+/* cubeMap.cu:6-31 for one direction: rgba[4], face index, (u, v). */
+ORC_API int orc_cubemap_color(const float *dir3, float *rgba, int *face, float *uv) {
+    if (!g_cube_set) return 1;
+    f4 c = cubemap_color(f4(dir3[0], dir3[1], dir3[2]), face, uv);
+    for (int k = 0; k < 4; k++) rgba[k] = c[k];
     return 0;
 }
 

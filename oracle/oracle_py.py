@@ -25,6 +25,8 @@ class Counters(C.Structure):
 
 lib.orc_trace_primary.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Counters)]
 lib.orc_trace_rays.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Counters)]
+lib.orc_set_cubemap.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+lib.orc_cubemap_color.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
 lib.orc_occluded.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
 lib.orc_render.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(Counters)]
 lib.orc_tri_precompute.argtypes = [C.c_void_p] * 5
@@ -60,6 +62,25 @@ def trace_rays(scene, rays, mode=BRUTE):
     rc = lib.orc_trace_rays(_soa_ptr(scene), n, rays.ctypes.data, mode, ids.ctypes.data, t.ctypes.data, nrm.ctypes.data, C.byref(cnt))
     assert rc == 0
     return ids, t, nrm, cnt
+
+
+def set_cubemap(faces):
+    """faces: six uint8 arrays [h, w, 3] (+x,-x,+y,-y,+z,-z), row 0 = bottom row; None clears."""
+    if faces is None:
+        assert lib.orc_set_cubemap(None, None, None) == 0
+        return
+    faces = [np.ascontiguousarray(f, np.uint8) for f in faces]
+    ptrs = (C.c_void_p * 6)(*[f.ctypes.data for f in faces])
+    w = (C.c_int * 6)(*[f.shape[1] for f in faces])
+    h = (C.c_int * 6)(*[f.shape[0] for f in faces])
+    assert lib.orc_set_cubemap(ptrs, w, h) == 0
+
+
+def cubemap_color(d):
+    d = (C.c_float * 3)(*[float(x) for x in d])
+    rgba, face, uv = (C.c_float * 4)(), C.c_int(), (C.c_float * 2)()
+    assert lib.orc_cubemap_color(d, rgba, C.byref(face), uv) == 0
+    return np.array(rgba[:], np.float32), face.value, np.array(uv[:], np.float32)
 
 
 def occluded(scene, rays, tmax):

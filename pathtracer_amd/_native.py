@@ -60,6 +60,11 @@ class Stats(C.Structure):
     ]
 
 
+class CubeMap(C.Structure):
+    """``mi_cubemap``."""
+    _fields_ = [("width", C.c_int32 * 6), ("height", C.c_int32 * 6), ("rgb", C.c_void_p * 6)]
+
+
 class BuildStats(C.Structure):
     """``mi_build_stats``."""
     _fields_ = [("ms_build", C.c_double), ("sah_cost", C.c_double), ("depth", C.c_int32), ("n_nodes", C.c_uint32)]
@@ -67,7 +72,7 @@ class BuildStats(C.Structure):
 
 MI_SYMBOLS = [
     "mi_ctx_create", "mi_ctx_destroy", "mi_scene_upload", "mi_scene_upload_build", "mi_scene_quality",
-    "mi_scene_download_nodes", "mi_render", "mi_render_device", "mi_shard_pixels",
+    "mi_scene_download_nodes", "mi_cubemap_upload", "mi_render", "mi_render_device", "mi_shard_pixels",
     "mi_assemble_rgb8", "mi_trace_primary", "mi_trace_rays", "mi_occluded_rays", "mi_last_error", "mi_abi_version",
 ]
 
@@ -104,6 +109,8 @@ mi.mi_occluded_rays.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C
 mi.mi_occluded_rays.restype = C.c_int
 mi.mi_scene_upload_build.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(BuildStats)]
 mi.mi_scene_upload_build.restype = C.c_int
+mi.mi_cubemap_upload.argtypes = [C.c_void_p, C.c_void_p]
+mi.mi_cubemap_upload.restype = C.c_int
 mi.mi_scene_quality.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
 mi.mi_scene_quality.restype = C.c_int
 mi.mi_scene_download_nodes.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_int32)]

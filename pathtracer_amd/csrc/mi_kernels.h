@@ -38,6 +38,9 @@ struct DevScene {
     int32_t root_ref;
     uint32_t n_tri, n_sph;
     float4 eye, u, v, look;
+    // Cubemap background or nullptr (white): 6 x (width, height, byte offset) as int32, then
+    // at byte 128 the RGB8 texels of the six faces (+x,-x,+y,-y,+z,-z; row 0 = bottom row).
+    const int32_t *cube;
 };
 
 struct f3 {
@@ -640,6 +643,45 @@ __device__ __forceinline__ f3 hemisphere(f3 N, float u1, float u2) {
     return sin_t * cos_p * a + sin_t * sin_p * b + cos_t * N;
 }
 
+// Background of a ray that hits nothing when a cubemap is loaded: CubeMap::getColor
+// (cubeMap.cu:6-31) + TextureMap::getMappedValue / getPixelAt (material.cu:20-37).  The
+// reference's f4 algebra is reduced to what is not identically zero: `forward`, `up`,
+// `right` are signed unit axes, so each dot product is +-one component of dir, exactly.
+__device__ __forceinline__ float4 cube_pixel(const int32_t *cube, const uint8_t *texels, int w, int h, int x, int y) {
+    x = max(0, min(w - 1, x));
+    y = max(0, min(h - 1, y));
+    const uint8_t *p = texels + ((size_t)x + (size_t)y * w) * 3;
+    return make_float4(p[0] / 256.0f, p[1] / 256.0f, p[2] / 256.0f, 0.0f);
+}
+__device__ __forceinline__ float4 cubemap_color(const int32_t *cube, f3 raydir) {
+    f3 dir = normalize3(raydir);                                     // :10
+    int ax = 2;                                                      // :11-15
+    if (__builtin_fabsf(dir.y) > __builtin_fabsf(dir.z)) ax = 1;
+    if (__builtin_fabsf(dir.x) > __builtin_fabsf(dir.z) && __builtin_fabsf(dir.x) > __builtin_fabsf(dir.y)) ax = 0;
+    const float major = ax == 0 ? dir.x : (ax == 1 ? dir.y : dir.z);
+    const float sgn = major < 0 ? -1.0f : 1.0f;
+    const float dn = sgn * major;                                    // dot(dir, forward), :20
+    dir = mk3(dir.x / dn, dir.y / dn, dir.z / dn);
+    const float m2 = ax == 0 ? dir.x : (ax == 1 ? dir.y : dir.z);
+    int face = 2 * ax;                                               // :23-25
+    if ((m2 < 0) != (ax == 2)) face++;
+    // :27-29 with forward = sgn*e_ax:  ax 0: up = +y, right = sgn*z;  ax 1: up = q*z (q = sign of
+    // dir[1] after the division = sgn), right = +x;  ax 2: up = +y, right = -sgn*x
+    float du, dr;
+    if (ax == 0) { du = dir.y; dr = sgn * dir.z; }
+    else if (ax == 1) { du = (m2 < 0 ? -1.0f : 1.0f) * dir.z; dr = dir.x; }
+    else { du = dir.y; dr = -sgn * dir.x; }
+    const float u = 0.5f + dr / 2.0f, v = 0.5f + du / 2.0f;
+    const int w = cube[3 * face], h = cube[3 * face + 1];
+    const uint8_t *texels = (const uint8_t *)cube + 128 + (uint32_t)cube[3 * face + 2];
+    const float x = u * (float)w, y = v * (float)h;                  // material.cu:21-29
+    const int xi = (int)x, yi = (int)y;
+    const float lx = x - (float)xi, ly = y - (float)yi;
+    const float4 xl = add4(mul4(lx, cube_pixel(cube, texels, w, h, xi + 1, yi)), mul4(1 - lx, cube_pixel(cube, texels, w, h, xi, yi)));
+    const float4 xr = add4(mul4(lx, cube_pixel(cube, texels, w, h, xi + 1, yi + 1)), mul4(1 - lx, cube_pixel(cube, texels, w, h, xi, yi + 1)));
+    return add4(mul4(ly, xr), mul4(1 - ly, xl));
+}
+
 // The reference evaluates radiance by recursion: value_k = ke_k*32 + w_k (.) value_{k+1}
 // (CpuTracer.cu:152,166,174,185).  To round exactly like it, every level stores
 // (e_k, w_k) and the terminating thread folds them from the deepest level back.
@@ -670,8 +712,9 @@ __device__ __forceinline__ uint64_t path_id(const ShardGeom &g, int px, int py, 
 __device__ __forceinline__ bool shade_path(const DevScene &sc, uint64_t seed, uint64_t path, int level, int depth_left, uint32_t slot,
                                            f3 o, f3 d, float4 T, float t, int pslot, float hu, float hv, float4 *hist,
                                            size_t cap, float4 *path_out, f3 &no, f3 &nd, float4 &Tn) {
-    if (pslot < 0) { // CpuTracer.cu:124-125: miss -> (1,1,1,1)
-        path_out[slot] = clamp01_4(fold_history(hist, cap, slot, level, make_float4(1.0f, 1.0f, 1.0f, 1.0f)));
+    if (pslot < 0) { // CpuTracer.cu:124-125: miss -> cubemap colour, or (1,1,1,1) without a cubemap
+        const float4 bg = sc.cube ? cubemap_color(sc.cube, d) : make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+        path_out[slot] = clamp01_4(fold_history(hist, cap, slot, level, bg));
         return false;
     }
     f3 N;

@@ -60,7 +60,7 @@ struct mi_ctx {
     bool has_scene = false;
     DevScene sc{};
     uint32_t n_nodes = 0;
-    DevBuf nodes, tri, tri_normal, tri_mat, tri_has_vmat, sph, sph_mat, mats, prim_id;
+    DevBuf nodes, tri, tri_normal, tri_mat, tri_has_vmat, sph, sph_mat, mats, prim_id, cube;
     // per-batch path state (sized by slot capacity / depth): two ray streams (level k reads
     // stream k&1 and writes stream (k+1)&1), hits by stream position, history and path value by slot
     DevBuf ray_o[2], ray_d[2], thr[2], hits, path_out, hist, counters, ovf, totals;
@@ -88,7 +88,7 @@ static const int kCounterWords = (kMaxLevels + 1) * kLevelWords + MI_CNT_STRIDE;
 
 static int extend_grid(const mi_ctx *c) { return c->n_cu * c->extend_wg_per_cu; }
 
-MI_API int mi_abi_version(void) { return 5; }
+MI_API int mi_abi_version(void) { return 6; }
 MI_API const char *mi_last_error(void) { return g_err.c_str(); }
 
 MI_API mi_status mi_ctx_create(int device_id, mi_ctx **out) {
@@ -135,7 +135,7 @@ MI_API void mi_ctx_destroy(mi_ctx *c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     DevBuf *all[] = {&c->nodes, &c->tri, &c->tri_normal, &c->tri_mat, &c->tri_has_vmat, &c->sph, &c->sph_mat, &c->mats,
-                     &c->prim_id, &c->ray_o[0], &c->ray_o[1], &c->ray_d[0], &c->ray_d[1], &c->thr[0], &c->thr[1], &c->hits,
+                     &c->prim_id, &c->cube, &c->ray_o[0], &c->ray_o[1], &c->ray_d[0], &c->ray_d[1], &c->thr[0], &c->thr[1], &c->hits,
                      &c->path_out, &c->hist, &c->counters, &c->ovf, &c->totals, &c->out_mean, &c->out_rgba8,
                      &c->out_rgb8, &c->probe_i, &c->probe_t, &c->probe_n};
     for (DevBuf *b : all) b->release();
@@ -776,5 +776,33 @@ MI_API mi_status mi_occluded_rays(mi_ctx *c, int64_t total, const float *rays, c
         HIPCHK(hipMemcpyAsync(occluded_out + first, c->probe_i.p, (size_t)n, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
     }
+    return MI_OK;
+}
+
+MI_API mi_status mi_cubemap_upload(mi_ctx *c, const mi_cubemap *cm) {
+    if (!c) return fail(MI_ERR_INVALID, "mi_cubemap_upload: ctx is NULL");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (!cm) { // back to the white background of CpuTracer.cu:125
+        c->sc.cube = nullptr;
+        return MI_OK;
+    }
+    size_t total = 0;
+    int32_t header[32] = {0};
+    for (int f = 0; f < 6; f++) {
+        if (!cm->rgb[f] || cm->width[f] <= 0 || cm->height[f] <= 0 || cm->width[f] > 32768 || cm->height[f] > 32768)
+            return fail(MI_ERR_INVALID, "mi_cubemap_upload: face %d missing or of bad size", f);
+        header[3 * f] = cm->width[f];
+        header[3 * f + 1] = cm->height[f];
+        header[3 * f + 2] = (int32_t)total;
+        total += ((size_t)cm->width[f] * cm->height[f] * 3 + 15) / 16 * 16;
+        if (total >= ((size_t)1 << 31)) return fail(MI_ERR_INVALID, "mi_cubemap_upload: cubemap larger than 2 GiB");
+    }
+    c->sc.cube = nullptr;
+    HIPCHK(c->cube.ensure(128 + total));
+    HIPCHK(hipMemcpy(c->cube.p, header, 128, hipMemcpyHostToDevice));
+    for (int f = 0; f < 6; f++)
+        HIPCHK(hipMemcpy((char *)c->cube.p + 128 + header[3 * f + 2], cm->rgb[f], (size_t)cm->width[f] * cm->height[f] * 3, hipMemcpyHostToDevice));
+    c->sc.cube = c->cube.as<int32_t>();
     return MI_OK;
 }

@@ -41,6 +41,19 @@ class Context:
         self.scene = scene
         return st
 
+    def set_cubemap(self, faces):
+        """faces: six uint8 arrays [h, w, 3] (+x,-x,+y,-y,+z,-z), row 0 = bottom row; None removes it."""
+        if faces is None:
+            N.check(N.mi.mi_cubemap_upload(self._h, None))
+            return
+        faces = [np.ascontiguousarray(f, np.uint8) for f in faces]
+        if len(faces) != 6 or any(f.ndim != 3 or f.shape[2] != 3 for f in faces):
+            raise ValueError("six [h, w, 3] uint8 faces")
+        cm = N.CubeMap()
+        for i, f in enumerate(faces):
+            cm.width[i], cm.height[i], cm.rgb[i] = f.shape[1], f.shape[0], f.ctypes.data
+        N.check(N.mi.mi_cubemap_upload(self._h, C.byref(cm)))
+
     def scene_quality(self):
         v = C.c_double()
         N.check(N.mi.mi_scene_quality(self._h, C.byref(v)))

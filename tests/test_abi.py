@@ -30,12 +30,12 @@ def test_every_declared_symbol_is_exported():
 
 def test_struct_layouts_match_the_header(tmp_path):
     prog = tmp_path / "sz.c"
-    prog.write_text('#include <stdio.h>\n#include "mi_tracer.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(mi_build_stats), sizeof(mi_scene_soa), '
+    prog.write_text('#include <stdio.h>\n#include "mi_tracer.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(mi_cubemap), sizeof(mi_build_stats), sizeof(mi_scene_soa), '
                     'sizeof(mi_render_params), sizeof(mi_stats), offsetof(mi_scene_soa, cam_eye), offsetof(mi_render_params, batch_paths));return 0;}\n')
     exe = tmp_path / "sz"
     subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(prog), "-o", str(exe)], check=True)
     out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()
-    assert [int(x) for x in out] == [C.sizeof(N.BuildStats), C.sizeof(N.SceneSoA), C.sizeof(N.RenderParams), C.sizeof(N.Stats),
+    assert [int(x) for x in out] == [C.sizeof(N.CubeMap), C.sizeof(N.BuildStats), C.sizeof(N.SceneSoA), C.sizeof(N.RenderParams), C.sizeof(N.Stats),
                                      N.SceneSoA.cam_eye.offset, N.RenderParams.batch_paths.offset]
 
 

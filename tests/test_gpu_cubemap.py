@@ -1,0 +1,53 @@
+"""Cubemap background on the device (CpuTracer.cu:125 + cubeMap.cu:6-31 +
+material.cu:20-37) against the oracle's restatement, bit for bit."""
+import numpy as np
+import pytest
+
+import pathtracer_amd as P
+from pathtracer_amd import scenes
+from oracle import oracle_py as O
+
+pytestmark = pytest.mark.gpu
+H = scenes.HEADER
+
+
+def same(a, b):
+    return np.array_equal(np.ascontiguousarray(a).view(np.uint32), np.ascontiguousarray(b).view(np.uint32))
+
+
+def random_faces(seed, sizes):
+    rng = np.random.default_rng(seed)
+    return [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for (w, h) in sizes]
+
+
+@pytest.mark.parametrize("sizes", [[(16, 16)] * 6, [(8, 12), (5, 3), (1, 1), (32, 7), (2, 2), (9, 9)]])
+def test_cubemap_background_matches_oracle(ctx, scenes_small, sizes):
+    faces = random_faces(7, sizes)
+    ctx.set_cubemap(faces)
+    O.set_cubemap(faces)
+    try:
+        inside = P.Scene.from_text(H + "camera { position = (0.3,0.2,0.1); viewdir = (0.2,0.1,-1); updir = (0,1,0); fov = 120; aspectratio = 1.5; }\n")
+        for sc, p in ((inside, P.Context.params(96, 64, 2, 0, seed=1)),                 # every ray misses: all six faces seen
+                      (scenes_small["simple"], P.Context.params(80, 81, 2, 4, seed=3)),  # misses after mirror / glass bounces
+                      (scenes_small["glass"], P.Context.params(64, 36, 2, 6, seed=4))):
+            ctx.upload(sc)
+            mean, rgb, st = ctx.render(p)
+            omean, orgb, cnt = O.render(sc, p)
+            assert st.rays_cast == cnt.rays and same(mean, omean) and np.array_equal(rgb, orgb)
+        assert len(np.unique(rgb.reshape(-1, 3), axis=0)) > 50
+        # the cubemap belongs to the context: removing it brings the white background back
+        ctx.set_cubemap(None)
+        O.set_cubemap(None)
+        ctx.upload(inside)
+        assert np.all(ctx.render(P.Context.params(16, 16, 1, 0))[0] == 1.0)
+    finally:
+        ctx.set_cubemap(None)
+        O.set_cubemap(None)
+
+
+def test_cubemap_rejects_bad_faces(ctx):
+    from pathtracer_amd import _native as N
+    cm = N.CubeMap()
+    assert N.mi.mi_cubemap_upload(ctx._h, __import__("ctypes").byref(cm)) == 1   # NULL faces, zero sizes
+    with pytest.raises(ValueError):
+        ctx.set_cubemap([np.zeros((2, 2, 3), np.uint8)] * 5)

@@ -220,3 +220,56 @@ def test_any_hit_known_answers():
                      [9, 9, 5, 0, 0, -1]], np.float32)
     tmax = np.array([3.9, 4.5, 100, 7.9, 8.0, 8.1, 100, 100], np.float32)
     assert O.occluded(sc, rays, tmax).tolist() == [0, 1, 1, 0, 1, 1, 0, 0]
+
+
+def _solid_faces(size=4):
+    cols = [(255, 0, 0), (0, 255, 0), (0, 0, 255), (255, 255, 0), (0, 255, 255), (255, 0, 255)]
+    return [np.tile(np.array(c, np.uint8), (size, size, 1)) for c in cols], cols
+
+
+def test_cubemap_face_selection_and_uv():
+    """cubeMap.cu:6-31: faces +x,-x,+y,-y at even/odd indices by sign, but +z -> 5 and -z -> 4
+    (`dir[idx/2] < 0 != (idx == 4)`); texel / 256 (material.cu:36)."""
+    faces, cols = _solid_faces()
+    O.set_cubemap(faces)
+    try:
+        for d, face in (((1, 0.2, 0.1), 0), ((-1, 0.2, 0.1), 1), ((0.1, 1, 0.2), 2), ((0.1, -1, 0.2), 3),
+                        ((0.1, 0.2, 1), 5), ((0.1, 0.2, -1), 4)):
+            rgba, f, uv = O.cubemap_color(d)
+            assert f == face
+            assert np.array_equal(rgba, np.array(cols[face] + (0,), np.float32) / np.float32(256))
+        # centre of the +x face; a direction towards its upper edge (up = +y) and its right edge (right = +z)
+        assert np.array_equal(O.cubemap_color((2, 0, 0))[2], [0.5, 0.5])
+        assert np.allclose(O.cubemap_color((1, 0.5, 0))[2], [0.5, 0.75])
+        assert np.allclose(O.cubemap_color((1, 0, 0.5))[2], [0.75, 0.5])
+        # -z face: right = +x... the reference gives right = -sgn * x = +x for sgn = -1
+        assert np.allclose(O.cubemap_color((0.5, 0, -1))[2], [0.75, 0.5])
+        # +y face: up = +z, right = +x
+        assert np.allclose(O.cubemap_color((0.5, 1, 0.25))[2], [0.75, 0.625])
+    finally:
+        O.set_cubemap(None)
+
+
+def test_cubemap_bilinear_fetch_and_clamp():
+    """material.cu:20-37 on a 2x2 face: x = u*w, truncation, weights, clamp to the edge."""
+    f = np.zeros((2, 2, 3), np.uint8)
+    f[0, 0] = 0; f[0, 1] = 64; f[1, 0] = 128; f[1, 1] = 192     # [row y][col x], row 0 = bottom
+    faces = [f] * 6
+    O.set_cubemap(faces)
+    try:
+        rgba, face, uv = O.cubemap_color((1, 0, 0))               # u = v = 0.5 -> x = y = 1.0 -> pixel (1,1), lerp 0
+        assert face == 0 and np.array_equal(rgba[:3], [0.75] * 3) and rgba[3] == 0
+        # u = 0.25 -> x = 0.5: halfway between columns 0 and 1; v = 0.25 -> y = 0.5
+        rgba, _, uv = O.cubemap_color((1, -0.5, -0.5))
+        assert np.array_equal(uv, [0.25, 0.25])
+        want = 0.5 * (0.5 * 192 + 0.5 * 128) + 0.5 * (0.5 * 64 + 0.5 * 0)
+        assert np.array_equal(rgba[:3], [np.float32(want / 256)] * 3)
+        # empty scene + cubemap: every pixel is the cubemap colour of its camera ray
+        sc = P.Scene.from_text(scenes.HEADER + "camera { position = (0,0,0); viewdir = (0,0,-1); updir = (0,1,0); fov = 90; aspectratio = 1; }\n")
+        mean, rgb, cnt = O.render(sc, P.Context.params(4, 4, 1, 0))
+        assert cnt.rays == 16 and np.all(mean[..., 3] == 0) and mean[..., 0].min() >= 0 and mean[..., 0].max() <= 0.75
+        assert len(np.unique(mean[..., 0])) > 4
+    finally:
+        O.set_cubemap(None)
+    mean, _, _ = O.render(sc, P.Context.params(4, 4, 1, 0))
+    assert np.all(mean == 1.0)
