@@ -23,7 +23,7 @@ $(LIB)/libmi_tracer.so: pathtracer_amd/csrc/mi_tracer.hip pathtracer_amd/csrc/mi
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ pathtracer_amd/csrc/mi_tracer.hip
 
 $(LIB)/libpt_host.so: $(HOST_SRC) $(HOST_HDR) $(LIB)/libmi_tracer.so
-	$(CXX) $(CXXFLAGS) -shared -o $@ $(HOST_SRC) -L$(LIB) -lmi_tracer -Wl,-rpath,'$$ORIGIN'
+	$(CXX) $(CXXFLAGS) -shared -o $@ $(HOST_SRC) -L$(LIB) -lmi_tracer -lz -Wl,-rpath,'$$ORIGIN'
 
 $(BIN)/ray: pathtracer_amd/host/ray_main.cpp $(LIB)/libpt_host.so
 	@mkdir -p $(BIN)

@@ -145,6 +145,12 @@ host.pt_hip_tracer_new.restype = C.c_void_p
 host.pt_tracer_free.argtypes = [C.c_void_p]
 host.pt_tracer_load_scene.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
 host.pt_tracer_load_scene.restype = C.c_int
+host.pt_tracer_load_cubemap.argtypes = [C.c_void_p, C.c_char_p]
+host.pt_tracer_load_cubemap.restype = C.c_int
+host.pt_read_image.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, C.c_size_t]
+host.pt_read_image.restype = C.c_int
+host.pt_match_cubemap.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
+host.pt_match_cubemap.restype = C.c_int
 host.pt_tracer_aspect.argtypes = [C.c_void_p]
 host.pt_tracer_aspect.restype = C.c_double
 host.pt_tracer_trace_setup.argtypes = [C.c_void_p, C.c_int, C.c_int]

@@ -71,6 +71,23 @@ PT_API pt::HipTracer *pt_hip_tracer_new(int depth, int samples, int device, unsi
     return t;
 }
 PT_API void pt_tracer_free(pt::HipTracer *t) { delete t; }
+PT_API int pt_tracer_load_cubemap(pt::HipTracer *t, const char *one_face_file) { return t->loadCubemap(one_face_file) ? 1 : 0; }
+// matchCubemapFiles for tests: 1 and the six names joined by '\n' in out (NUL terminated) on success
+PT_API int pt_match_cubemap(const char *one, char *out, size_t cap) {
+    std::string names[6], dir, joined;
+    if (!pt::matchCubemapFiles(one, names, dir)) return 0;
+    for (int i = 0; i < 6; i++) joined += names[i] + (i < 5 ? "\n" : "");
+    if (joined.size() + 1 > cap) return 0;
+    memcpy(out, joined.c_str(), joined.size() + 1);
+    return 1;
+}
+// readImage for tests: returns 1 and fills w,h; rgb (w*h*3, row 0 = bottom) is copied into out when out != NULL and cap is large enough
+PT_API int pt_read_image(const char *path, int *w, int *h, unsigned char *out, size_t cap) {
+    std::vector<unsigned char> rgb;
+    if (!pt::readImage(path, *w, *h, rgb)) return 0;
+    if (out && cap >= rgb.size()) memcpy(out, rgb.data(), rgb.size());
+    return 1;
+}
 PT_API int pt_tracer_load_scene(pt::HipTracer *t, const char *text_or_path, int is_path) {
     bool ok = is_path ? t->loadScene(text_or_path) : t->loadSceneText(text_or_path);
     if (!ok) g_err = t->error();

@@ -2,20 +2,23 @@
 // (src/main.cu:7-14, src/ui/CommandLineUI.cu:21-101) with the MI355X backend as
 // the tracer.  getopt string "t:r:w:hj:c:s:gq:" is accepted unchanged; -g selects
 // the GPU backend in the reference and is implied here (the only backend), -q
-// (CUDA threads per block) is accepted and ignored, -j/-c are accepted and
-// ignored (JSON overrides and cubemaps are outside this backend's scope).
+// (CUDA threads per block) is accepted and ignored, -j is accepted and ignored (JSON
+// overrides are outside this backend's scope), -c <one of the six face files> loads the
+// cubemap background (CommandLineUI.cu:40-42,66-68).
 // Added: -G <device>, -S <seed>, -B (build the BVH on the GPU).
 #include <unistd.h>
 
 #include <cmath>
 #include <cstdlib>
 #include <iostream>
+#include <string>
 
 #include "tracer.h"
 
 int main(int argc, char **argv) {
     pt::TraceOptions o;
     int size = 512; // TraceUI.h:55
+    std::string cubemap;
     int c;
     while ((c = getopt(argc, argv, "t:r:w:hj:c:s:gq:G:S:B")) != -1) {
         switch (c) {
@@ -26,7 +29,8 @@ int main(int argc, char **argv) {
             case 'G': o.device = atoi(optarg); break;
             case 'S': o.seed = strtoull(optarg, nullptr, 10); break;
             case 'B': o.device_bvh = true; break;
-            case 'j': case 'c': case 'q': case 'g': break;
+            case 'c': cubemap = optarg; break;   // CommandLineUI.cu:40-42
+            case 'j': case 'q': case 'g': break;
             default:
                 std::cerr << "usage: " << argv[0] << " [options] [input.ray output.png]\n"
                           << "  -r <#>  recursion level (default 0)\n  -w <#>  image width (default 512)\n"
@@ -41,6 +45,7 @@ int main(int argc, char **argv) {
     const char *rayName = argv[optind], *imgName = argv[optind + 1];
     pt::HipTracer tracer(o);
     if (!tracer.ok()) return 2;
+    if (!cubemap.empty()) tracer.loadCubemap(cubemap.c_str()); // CommandLineUI.cu:66-68; a failure is reported and the render goes on without it
     if (!tracer.loadScene(rayName)) { // CommandLineUI.cu:82,96-100
         std::cerr << "Unable to load ray file '" << rayName << "'" << std::endl;
         return 1;

@@ -2,6 +2,8 @@
 // backend that drives libmi_tracer.so through its C-ABI.
 #include "tracer.h"
 
+#include <dirent.h>
+
 #include <algorithm>
 #include <cstring>
 #include <iostream>
@@ -53,6 +55,63 @@ void Tracer::traceSetup(int w, int h) { // tracer.cu:87-93
     std::fill(buffer.begin(), buffer.end(), 0);
 }
 
+// TraceUI.cu:70-148: the six names are recognised by "pos"/"neg" followed (anywhere later)
+// by the axis letter; only names containing ".bmp" or ".png" are looked at; two files for
+// one face stop the search.
+bool matchCubemapFiles(const std::string &one, std::string matched[6], std::string &dir) {
+    static const char *matcher[6][2] = {{"pos", "x"}, {"neg", "x"}, {"pos", "y"}, {"neg", "y"}, {"pos", "z"}, {"neg", "z"}};
+    static const char *exts[2] = {".bmp", ".png"};
+    dir = one.substr(0, one.find_last_of("/"));
+    DIR *dp = opendir(dir.c_str());
+    if (!dp) {
+        std::cerr << "Couldn't open the directory " << dir << std::endl;
+        return false;
+    }
+    for (int i = 0; i < 6; i++) matched[i].clear();
+    int n = 0;
+    while (struct dirent *ep = readdir(dp)) {
+        std::string fn(ep->d_name);
+        bool ext_ok = false;
+        for (const char *e : exts) ext_ok = ext_ok || fn.find(e) != std::string::npos;
+        if (!ext_ok) continue;
+        for (int i = 0; i < 6; i++) {
+            size_t p0 = fn.find(matcher[i][0]);
+            if (p0 == std::string::npos || fn.find(matcher[i][1], p0) == std::string::npos) continue;
+            if (!matched[i].empty()) {
+                closedir(dp);
+                std::cerr << matcher[i][0] << matcher[i][1] << " matches " << matched[i] << " and " << fn
+                          << ", stop smartload to avoid confliction" << std::endl;
+                return false;
+            }
+            matched[i] = fn;
+            n++;
+            break;
+        }
+        if (n == 6) break;
+    }
+    closedir(dp);
+    if (n != 6) {
+        std::cerr << "Cannot locate all six cubemap files" << std::endl;
+        return false;
+    }
+    return true;
+}
+
+bool Tracer::loadCubemap(const char *oneFaceFile) { // TraceUI.cu:150-169
+    std::string names[6], dir;
+    has_cube_ = false;
+    if (!matchCubemapFiles(oneFaceFile, names, dir)) return false;
+    for (int i = 0; i < 6; i++) {
+        const std::string path = dir + "/" + names[i];
+        if (!readImage(path.c_str(), cube_[i].w, cube_[i].h, cube_[i].rgb)) {
+            std::cerr << "Unable to load texture map '" << path << "'." << std::endl; // material.cu:13-16
+            return false;
+        }
+    }
+    has_cube_ = true;
+    return cubemapLoaded();
+}
+
 // ------------------------------------------------------------------ HipTracer
 HipTracer::HipTracer(const TraceOptions &o) : Tracer(o), opts_(o) {
     status_ = mi_ctx_create(o.device, &ctx_);
@@ -65,6 +124,19 @@ HipTracer::HipTracer(const TraceOptions &o) : Tracer(o), opts_(o) {
 HipTracer::~HipTracer() {
     if (worker_.joinable()) worker_.join();
     if (ctx_) mi_ctx_destroy(ctx_);
+}
+
+bool HipTracer::cubemapLoaded() {
+    if (!ctx_) return false;
+    mi_cubemap cm;
+    for (int i = 0; i < 6; i++) { cm.width[i] = cube_[i].w; cm.height[i] = cube_[i].h; cm.rgb[i] = cube_[i].rgb.data(); }
+    status_ = mi_cubemap_upload(ctx_, &cm);
+    if (status_ != MI_OK) {
+        error_ = mi_last_error();
+        std::cerr << "HipTracer: " << error_ << std::endl;
+        return false;
+    }
+    return true;
 }
 
 bool HipTracer::sceneLoaded() { // upload replaces Scene::clone, GpuTracer.cu:172-175

@@ -34,6 +34,10 @@ public:
     double aspectRatio();                         // tracer.cu:38-40
     bool loadScene(const char *fn);               // tracer.cu:42-85 (errors -> stderr, false)
     bool loadSceneText(const std::string &text);  // same, from memory
+    // TraceUI::smartLoadCubemap (TraceUI.cu:150-169): given ONE of the six face files, finds the
+    // others in its directory by name ("pos"/"neg" followed by "x"/"y"/"z", .bmp/.png) and loads
+    // them.  Errors go to stderr and leave the tracer without a cubemap, as in the reference.
+    bool loadCubemap(const char *oneFaceFile);
     void traceSetup(int w, int h);                // tracer.cu:87-93
     virtual void traceImage(int w, int h) = 0;    // tracer.h:35
     virtual void waitRender() = 0;                // tracer.h:37
@@ -42,6 +46,10 @@ public:
 
 protected:
     virtual bool sceneLoaded() { return true; }
+    virtual bool cubemapLoaded() { return true; }
+    struct Face { int w = 0, h = 0; std::vector<unsigned char> rgb; };
+    Face cube_[6];
+    bool has_cube_ = false;
     unsigned depth;
     unsigned samples;
     Scene *scene = nullptr;
@@ -66,6 +74,7 @@ public:
 
 protected:
     bool sceneLoaded() override;
+    bool cubemapLoaded() override;
 
 private:
     TraceOptions opts_;
@@ -80,5 +89,10 @@ private:
 // anything else -> BMP; rows are flipped so that buffer row 0 is the bottom row
 // (src/fileio/pngimage.cu:258-268, src/fileio/bitmap.cu:95-149).
 bool writeImage(const char *path, int w, int h, const unsigned char *rgb);
+// Counterpart of readImage (src/fileio/images.cu:51-57): ".bmp" (24 bit) or ".png" (8 bit) ->
+// RGB8, row 0 = bottom row.  false on anything else.
+bool readImage(const char *path, int &w, int &h, std::vector<unsigned char> &rgb);
+// TraceUI::matchCubemapFiles (TraceUI.cu:86-148).
+bool matchCubemapFiles(const std::string &one, std::string matched[6], std::string &dir);
 
 } // namespace pt

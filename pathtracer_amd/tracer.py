@@ -145,6 +145,10 @@ class HipTracer:
         arg = (str(path).encode(), 1) if path is not None else (text.encode(), 0)
         return bool(N.host.pt_tracer_load_scene(self._h, *arg))
 
+    def load_cubemap(self, one_face_file):
+        """TraceUI::smartLoadCubemap: one of the six face files names the directory."""
+        return bool(N.host.pt_tracer_load_cubemap(self._h, str(one_face_file).encode()))
+
     def aspect_ratio(self):
         return N.host.pt_tracer_aspect(self._h)
 
@@ -168,3 +172,21 @@ class HipTracer:
         st = N.Stats()
         N.host.pt_tracer_stats(self._h, C.byref(st))
         return st
+
+
+def read_image(path):
+    """readImage of the host library: uint8[h, w, 3], row 0 = bottom row; None if unreadable."""
+    w, h = C.c_int(), C.c_int()
+    if not N.host.pt_read_image(str(path).encode(), C.byref(w), C.byref(h), None, 0):
+        return None
+    out = np.empty((h.value, w.value, 3), np.uint8)
+    assert N.host.pt_read_image(str(path).encode(), C.byref(w), C.byref(h), out.ctypes.data, out.nbytes)
+    return out
+
+
+def match_cubemap_files(one_face_file):
+    """matchCubemapFiles of the host library: the six file names (+x,-x,+y,-y,+z,-z) or None."""
+    buf = C.create_string_buffer(8192)
+    if not N.host.pt_match_cubemap(str(one_face_file).encode(), buf, len(buf)):
+        return None
+    return buf.value.decode().split("\n")

@@ -51,3 +51,37 @@ def test_cubemap_rejects_bad_faces(ctx):
     assert N.mi.mi_cubemap_upload(ctx._h, __import__("ctypes").byref(cm)) == 1   # NULL faces, zero sizes
     with pytest.raises(ValueError):
         ctx.set_cubemap([np.zeros((2, 2, 3), np.uint8)] * 5)
+
+
+def test_cli_and_tracer_load_cubemap_files(tmp_path, scenes_small):
+    """`ray -c <one face file>` (CommandLineUI.cu:40-42,66-68 -> TraceUI::smartLoadCubemap) and
+    pt::Tracer::loadCubemap: the faces are found by name, read bottom-up, and the render
+    equals the oracle's with the same six arrays."""
+    import os
+    import subprocess
+    from PIL import Image
+    faces = random_faces(21, [(12, 12), (12, 12), (7, 9), (12, 12), (6, 5), (12, 12)])
+    names = ["cm_posx.png", "cm_negx.bmp", "cm_posy.png", "cm_negy.png", "cm_posz.bmp", "cm_negz.png"]
+    for f, n in zip(faces, names):
+        Image.fromarray(f[::-1]).save(tmp_path / n)            # files are top-down, faces are bottom-up
+    ray = tmp_path / "s.ray"
+    ray.write_text(scenes.simple_ray())
+    out = tmp_path / "s.png"
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pathtracer_amd", "bin", "ray")
+    r = subprocess.run([exe, "-r", "3", "-w", "64", "-s", "2", "-S", "9", "-c", str(tmp_path / names[3]), str(ray), str(out)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    O.set_cubemap(faces)
+    try:
+        want = O.render(scenes_small["simple"], P.Context.params(64, 65, 2, 3, seed=9))[1]
+    finally:
+        O.set_cubemap(None)
+    img = np.array(Image.open(out))
+    assert np.array_equal(img[::-1], want)
+    t = P.HipTracer(depth=3, samples=2, seed=9)
+    assert t.load_cubemap(tmp_path / names[0]) and t.load_scene(path=ray)
+    t.trace_setup(64, 65)
+    t.trace_image(64, 65)
+    t.wait_render()
+    assert np.array_equal(t.get_buffer(), want)
+    assert not t.load_cubemap(tmp_path / "nowhere" / "posx.png")
