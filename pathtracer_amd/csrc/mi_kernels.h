@@ -987,6 +987,16 @@ k_probe_occluded(int64_t n, const float4 *hits, uint8_t *out) {
     if (i < n) out[i] = __float_as_int(hits[i].y) >= 0 ? 1 : 0;
 }
 
+// Shard-local mean radiance -> frame order (i + j*W), for mi_render's host output.
+__global__ void __launch_bounds__(MI_BLOCK)
+k_unpermute_mean(ShardGeom g, int64_t local, const float4 *mean_local, float4 *mean_frame) {
+    int64_t q = (int64_t)blockIdx.x * MI_BLOCK + threadIdx.x;
+    if (q >= local) return;
+    int px, py;
+    if (!local_to_pixel(g, (uint32_t)q, px, py)) return;
+    mean_frame[(size_t)px + (size_t)py * g.width] = mean_local[q];
+}
+
 // Gathered shard-local RGBA8 -> bottom-up RGB8 frame (tracer.cu:96 layout).
 __global__ void __launch_bounds__(MI_BLOCK)
 k_assemble(ShardGeom g, const uchar4 *gathered, int64_t shard_stride, int64_t shard_pixels, uint8_t *rgb8) {

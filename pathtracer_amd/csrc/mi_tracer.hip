@@ -65,7 +65,7 @@ struct mi_ctx {
     // stream k&1 and writes stream (k+1)&1), hits by stream position, history and path value by slot
     DevBuf ray_o[2], ray_d[2], thr[2], hits, path_out, hist, counters, ovf, totals;
     // outputs for the host-pointer entry points
-    DevBuf out_mean, out_rgba8, out_rgb8, probe_i, probe_t, probe_n;
+    DevBuf out_mean, out_rgba8, out_rgb8, out_mean_frame, probe_i, probe_t, probe_n;
     std::vector<hipEvent_t> ev;
     uint64_t *h_totals = nullptr; // pinned
     // tuning knobs (defaults measured on MI355X, overridable through the environment)
@@ -137,7 +137,7 @@ MI_API void mi_ctx_destroy(mi_ctx *c) {
     DevBuf *all[] = {&c->nodes, &c->tri, &c->tri_normal, &c->tri_mat, &c->tri_has_vmat, &c->sph, &c->sph_mat, &c->mats,
                      &c->prim_id, &c->cube, &c->ray_o[0], &c->ray_o[1], &c->ray_d[0], &c->ray_d[1], &c->thr[0], &c->thr[1], &c->hits,
                      &c->path_out, &c->hist, &c->counters, &c->ovf, &c->totals, &c->out_mean, &c->out_rgba8,
-                     &c->out_rgb8, &c->probe_i, &c->probe_t, &c->probe_n};
+                     &c->out_rgb8, &c->out_mean_frame, &c->probe_i, &c->probe_t, &c->probe_n};
     for (DevBuf *b : all) b->release();
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     if (c->h_totals) (void)hipHostFree(c->h_totals);
@@ -634,7 +634,29 @@ MI_API mi_status mi_render(mi_ctx *c, const mi_render_params *p, float *rgba_mea
     HIPCHK(c->out_rgba8.ensure(std::max<size_t>((size_t)local * 4, 16)));
     mi_status rs = mi_render_device(c, p, rgba_mean_out ? c->out_mean.p : nullptr, rgb8_out ? c->out_rgba8.p : nullptr, nullptr, stats);
     if (rs != MI_OK) return rs;
-    // un-permute shard-local order into the caller's full-frame buffers
+    if (g.count == 1) {
+        // the whole frame is ours: un-permute on the device, then one copy per output
+        hipStream_t st = c->stream;
+        const size_t npx = (size_t)g.width * g.height;
+        if (rgb8_out) {
+            HIPCHK(c->out_rgb8.ensure(npx * 3));
+            hipLaunchKernelGGL(k_assemble, dim3((unsigned)((local + MI_BLOCK - 1) / MI_BLOCK)), dim3(MI_BLOCK), 0, st, g, c->out_rgba8.as<uchar4>(),
+                               (int64_t)local, (int64_t)local, c->out_rgb8.as<uint8_t>());
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(rgb8_out, c->out_rgb8.p, npx * 3, hipMemcpyDeviceToHost, st));
+        }
+        if (rgba_mean_out) {
+            HIPCHK(c->out_mean_frame.ensure(npx * 16));
+            hipLaunchKernelGGL(k_unpermute_mean, dim3((unsigned)((local + MI_BLOCK - 1) / MI_BLOCK)), dim3(MI_BLOCK), 0, st, g, (int64_t)local,
+                               c->out_mean.as<float4>(), c->out_mean_frame.as<float4>());
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(rgba_mean_out, c->out_mean_frame.p, npx * 16, hipMemcpyDeviceToHost, st));
+        }
+        HIPCHK(hipStreamSynchronize(st));
+        return MI_OK;
+    }
+    // a shard of the frame: pixels of tiles it does not own must stay untouched in the caller's
+    // buffers, so its tiles are scattered on the host
     std::vector<float> mean;
     std::vector<uint8_t> rgba;
     if (rgba_mean_out) { mean.resize((size_t)local * 4); HIPCHK(hipMemcpy(mean.data(), c->out_mean.p, (size_t)local * 16, hipMemcpyDeviceToHost)); }
