@@ -11,6 +11,10 @@
  * status codes.  No C++ types, no exceptions, no torch types cross it.
  *
  * All colour/vector data is fp32.  "float4" below means 4 consecutive floats.
+ *
+ * Threading: a context owns its device buffers and is used by one call at a time (the
+ * reference's caller is single-threaded, CommandLineUI.cu:82-94); different contexts,
+ * also on the same GPU, are independent.  Error strings are per thread.
  */
 #ifndef MI_TRACER_H
 #define MI_TRACER_H

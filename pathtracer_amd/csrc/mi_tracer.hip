@@ -203,6 +203,15 @@ static mi_status validate_scene(const mi_scene_soa *s) {
     return MI_OK;
 }
 
+static mi_status get_events(mi_ctx *c, size_t n) {
+    while (c->ev.size() < n) {
+        hipEvent_t e;
+        HIPCHK(hipEventCreate(&e));
+        c->ev.push_back(e);
+    }
+    return MI_OK;
+}
+
 // Copies primitives, materials, ids and camera (everything but the nodes) to the device.
 static mi_status upload_prims(mi_ctx *c, const mi_scene_soa *s) {
     const size_t nt = s->n_tri, ns = s->n_sph;
@@ -356,9 +365,9 @@ MI_API mi_status mi_scene_upload_build(mi_ctx *c, const mi_scene_soa *s, const f
         HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, cub_bytes, keys_a.as<uint64_t>(), keys_b.as<uint64_t>(), vals_a.as<uint32_t>(),
                                                   vals_b.as<uint32_t>(), (int)n, 0, 62, st));
         HIPCHK(cub_tmp.ensure(std::max<size_t>(cub_bytes, 16)));
-        hipEvent_t e0, e1;
-        HIPCHK(hipEventCreate(&e0));
-        HIPCHK(hipEventCreate(&e1));
+        mi_status evs = get_events(c, 2); // the context's first two events bracket the build
+        if (evs != MI_OK) return evs;
+        hipEvent_t e0 = c->ev[0], e1 = c->ev[1];
         const float init_box[8] = {3.0e38f, 3.0e38f, 3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f, 0, 0};
         HIPCHK(hipMemcpyAsync(sbox.p, init_box, 32, hipMemcpyHostToDevice, st));
         HIPCHK(hipStreamSynchronize(st)); // host sources above are stack/borrowed memory
@@ -392,8 +401,6 @@ MI_API mi_status mi_scene_upload_build(mi_ctx *c, const mi_scene_soa *s, const f
         HIPCHK(hipStreamSynchronize(st));
         float ms = 0;
         HIPCHK(hipEventElapsedTime(&ms, e0, e1));
-        (void)hipEventDestroy(e0);
-        (void)hipEventDestroy(e1);
         if (h_root > MI_MAX_STACK) return fail(MI_ERR_INVALID, "device-built BVH is %d levels deep (limit %d)", h_root, MI_MAX_STACK);
         if (stats) {
             const double a = 2.0 * (dx * dy + dy * dz + dz * dx);
@@ -445,14 +452,6 @@ MI_API int64_t mi_shard_pixels(const mi_render_params *p) {
     return shard_pixels(g);
 }
 
-static mi_status get_events(mi_ctx *c, size_t n) {
-    while (c->ev.size() < n) {
-        hipEvent_t e;
-        HIPCHK(hipEventCreate(&e));
-        c->ev.push_back(e);
-    }
-    return MI_OK;
-}
 
 __global__ void k_sum_counts(const uint32_t *counts, int n, uint64_t *totals, const uint32_t *tail_level) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
