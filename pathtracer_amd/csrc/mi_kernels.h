@@ -21,7 +21,8 @@
 
 #define MI_BLOCK 256          // threads per workgroup = 4 waves of 64
 #define MI_LDS_STACK 16       // traversal stack entries per lane held in LDS
-#define MI_MAX_STACK 64       // deepest tree the uploader accepts
+#define MI_MAX_DEPTH 64       // deepest (binary) tree the uploader accepts
+#define MI_MAX_STACK 192      // up to three pushes per level of the 4-wide tree collapsed from it
 #define MI_NO_HIT 12345678.9f // ray.h:14
 #define MI_EPS 0.00001f       // ray.h:12
 
@@ -379,7 +380,7 @@ __device__ __forceinline__ bool tail_took_over(const uint32_t *tail_level, int l
 struct Lane {
     f3 o, d, inv, noi; // noi = -(o * inv), for the fast slab test
     Hit h;
-    int cur, sp, pend0, pend1;
+    int cur, sp; // cur: >= 0 node to visit, < 0 leaf ~cur to test, MI_DONE finished
     bool exact;
 };
 __device__ __forceinline__ void lane_start(const DevScene &sc, Lane &L, f3 o, f3 d, float t0 = MI_NO_HIT) {
@@ -392,63 +393,84 @@ __device__ __forceinline__ void lane_start(const DevScene &sc, Lane &L, f3 o, f3
                 __builtin_fabsf(L.noi.x) < 1e30f && __builtin_fabsf(L.noi.y) < 1e30f && __builtin_fabsf(L.noi.z) < 1e30f);
     L.h = Hit{t0, 0.0f, 0.0f, -1};
     L.sp = 0;
-    L.pend0 = L.pend1 = MI_NONE;
-    if (sc.n_tri + sc.n_sph == 0) {       // bvh.cu:174-176,180-181
-        L.cur = MI_DONE;
-    } else if (sc.root_ref < 0) {         // bvh.cu:182-183
-        L.pend0 = ~sc.root_ref;
-        L.cur = MI_DONE;
-    } else {
-        L.cur = sc.root_ref;
-    }
+    // bvh.cu:174-176,180-183: nothing to hit / a single primitive / a tree
+    L.cur = sc.n_tri + sc.n_sph == 0 ? MI_DONE : sc.root_ref;
 }
-// Node phase of one lane: fetch node L.cur (64 B), slab-test both child boxes, queue
-// leaf children as pending, descend near-first / pop (bvh.cu:178-207 restructured).
 typedef __attribute__((address_space(3))) int lds_int; // LDS-qualified, so stack accesses can only be ds_read/ds_write
-__device__ __forceinline__ void node_phase(const DevScene &sc, Lane &L, lds_int *stack, int *my_ovf, size_t ovf_stride) {
-    const char *nd = (const char *)sc.nodes + ((uint32_t)L.cur << 6);
-    float4 n0 = *(const float4 *)(nd), n1 = *(const float4 *)(nd + 16), n2 = *(const float4 *)(nd + 32);
-    int2 refs = *(const int2 *)(nd + 48);
-    float tminL, tminR;
-    bool hitL, hitR;
-    if (L.exact) {
-        hitL = slab_exact(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), L.o, L.inv, L.h.t, tminL);
-        hitR = slab_exact(mk3(n1.z, n1.w, n2.x), mk3(n2.y, n2.z, n2.w), L.o, L.inv, L.h.t, tminR);
-    } else {
-        hitL = slab_fast(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), L.inv, L.noi, L.h.t, tminL);
-        hitR = slab_fast(mk3(n1.z, n1.w, n2.x), mk3(n2.y, n2.z, n2.w), L.inv, L.noi, L.h.t, tminR);
-    }
-    int l = refs.x, r = refs.y;
-    if (hitL && l < 0) L.pend0 = ~l;
-    if (hitR && r < 0) { if (L.pend0 == MI_NONE) L.pend0 = ~r; else L.pend1 = ~r; }
-    bool goL = hitL && l >= 0, goR = hitR && r >= 0;
-    if (goL && goR) {
-        if (tminR < tminL) { int tmp = l; l = r; r = tmp; }
-        if (L.sp < MI_LDS_STACK) stack[L.sp * MI_BLOCK] = r;
-        else my_ovf[(size_t)(L.sp - MI_LDS_STACK) * ovf_stride] = r;
-        L.sp++;
-        L.cur = l;
-    } else if (goL) {
-        L.cur = l;
-    } else if (goR) {
-        L.cur = r;
-    } else if (L.sp == 0) {
+// Pop the next node / leaf (MI_DONE when the stack is empty).  The LDS read is
+// unconditional (clamped index) and the rare overflow entry overrides it: a `?:` over the
+// two address spaces compiles to one flat_load, which is slower than ds_read and makes
+// every later wait cover both counters (hence also the LDS-qualified pointer type).
+__device__ __forceinline__ void lane_pop(Lane &L, lds_int *stack, int *my_ovf, size_t ovf_stride) {
+    if (L.sp == 0) {
         L.cur = MI_DONE;
     } else {
-        // The LDS read is unconditional (clamped index) and the rare overflow entry
-        // overrides it: a `?:` over the two address spaces compiles to one flat_load,
-        // which is slower than ds_read and makes every later wait cover both counters
-        // (hence also the LDS-qualified pointer type).
         L.sp--;
         int top = stack[(L.sp < MI_LDS_STACK ? L.sp : MI_LDS_STACK - 1) * MI_BLOCK];
         if (L.sp >= MI_LDS_STACK) top = my_ovf[(size_t)(L.sp - MI_LDS_STACK) * ovf_stride];
         L.cur = top;
     }
 }
-__device__ __forceinline__ void leaf_phase(const DevScene &sc, Lane &L) { // one pending primitive
-    prim_test(sc, L.pend0, L.o, L.d, L.h);
-    L.pend0 = L.pend1;
-    L.pend1 = MI_NONE;
+__device__ __forceinline__ void lane_push(Lane &L, lds_int *stack, int *my_ovf, size_t ovf_stride, int ref) {
+    if (L.sp < MI_LDS_STACK) stack[L.sp * MI_BLOCK] = ref;
+    else my_ovf[(size_t)(L.sp - MI_LDS_STACK) * ovf_stride] = ref;
+    L.sp++;
+}
+// Node phase of one lane: fetch the 4-wide node L.cur (128 B: lo.x[4], lo.y[4], lo.z[4],
+// hi.x[4], hi.y[4], hi.z[4], refs[4], pad), slab-test the four child boxes, continue with the
+// nearest child that is hit and push the others, farthest first.  A child ref >= 0 is a node,
+// < 0 a leaf (~slot), MI_DONE an empty seat.  (bvh.cu:178-207 restructured; the 4-wide nodes
+// are collapsed from the caller's binary tree at upload, mi_tracer.hip.)
+__device__ __forceinline__ void cswap(bool sw, float &ka, float &kb, int &ra, int &rb) {
+    const float k0 = sw ? kb : ka, k1 = sw ? ka : kb;
+    const int r0 = sw ? rb : ra, r1 = sw ? ra : rb;
+    ka = k0; kb = k1; ra = r0; rb = r1;
+}
+__device__ __forceinline__ void node_phase(const DevScene &sc, Lane &L, lds_int *stack, int *my_ovf, size_t ovf_stride) {
+    const char *nd = (const char *)sc.nodes + ((uint32_t)L.cur << 7);
+    const float4 lx = *(const float4 *)(nd), ly = *(const float4 *)(nd + 16), lz = *(const float4 *)(nd + 32);
+    const float4 hx = *(const float4 *)(nd + 48), hy = *(const float4 *)(nd + 64), hz = *(const float4 *)(nd + 80);
+    const int4 refs = *(const int4 *)(nd + 96);
+    const float LX[4] = {lx.x, lx.y, lx.z, lx.w}, LY[4] = {ly.x, ly.y, ly.z, ly.w}, LZ[4] = {lz.x, lz.y, lz.z, lz.w};
+    const float HX[4] = {hx.x, hx.y, hx.z, hx.w}, HY[4] = {hy.x, hy.y, hy.z, hy.w}, HZ[4] = {hz.x, hz.y, hz.z, hz.w};
+    int R[4] = {refs.x, refs.y, refs.z, refs.w};
+    float K[4]; // entry distance of a child that is hit, +inf otherwise
+    if (L.exact) {
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            float tmin;
+            const bool hit = slab_exact(mk3(LX[c], LY[c], LZ[c]), mk3(HX[c], HY[c], HZ[c]), L.o, L.inv, L.h.t, tmin);
+            K[c] = (hit && R[c] != MI_DONE) ? tmin : __builtin_inff();
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            float tmin;
+            const bool hit = slab_fast(mk3(LX[c], LY[c], LZ[c]), mk3(HX[c], HY[c], HZ[c]), L.inv, L.noi, L.h.t, tmin);
+            K[c] = (hit && R[c] != MI_DONE) ? tmin : __builtin_inff();
+        }
+    }
+    // sorting network, descending by entry distance: K[0] farthest ... K[3] nearest
+    cswap(K[0] < K[1], K[0], K[1], R[0], R[1]);
+    cswap(K[2] < K[3], K[2], K[3], R[2], R[3]);
+    cswap(K[0] < K[2], K[0], K[2], R[0], R[2]);
+    cswap(K[1] < K[3], K[1], K[3], R[1], R[3]);
+    cswap(K[1] < K[2], K[1], K[2], R[1], R[2]);
+    // children that are not hit have K = +inf and sort to the front; push the hit ones of
+    // K[0..2] (farthest first), continue with K[3] if it is hit, else pop
+    const float inf = __builtin_inff();
+    if (K[3] < inf) {
+        if (K[0] < inf) lane_push(L, stack, my_ovf, ovf_stride, R[0]);
+        if (K[1] < inf) lane_push(L, stack, my_ovf, ovf_stride, R[1]);
+        if (K[2] < inf) lane_push(L, stack, my_ovf, ovf_stride, R[2]);
+        L.cur = R[3];
+    } else {
+        lane_pop(L, stack, my_ovf, ovf_stride);
+    }
+}
+__device__ __forceinline__ void leaf_phase(const DevScene &sc, Lane &L, lds_int *stack, int *my_ovf, size_t ovf_stride) { // one primitive
+    prim_test(sc, ~L.cur, L.o, L.d, L.h);
+    lane_pop(L, stack, my_ovf, ovf_stride);
 }
 
 // Persistent waves, per-lane ray refill, and leaf tests postponed to their own phase.
@@ -507,7 +529,7 @@ k_extend(DevScene sc, const uint32_t *count_ptr, uint32_t fixed_count, uint32_t 
     bool active = false;
     uint32_t slot = 0;
     Lane L;
-    L.cur = MI_DONE; L.sp = 0; L.pend0 = L.pend1 = MI_NONE; L.exact = false;
+    L.cur = MI_DONE; L.sp = 0; L.exact = false;
     L.h = Hit{MI_NO_HIT, 0.0f, 0.0f, -1};
     L.o = L.d = L.inv = L.noi = mk3(0, 0, 0);
     unsigned long long act = 0ull; // ballot of `active`
@@ -554,27 +576,27 @@ k_extend(DevScene sc, const uint32_t *count_ptr, uint32_t fixed_count, uint32_t 
             more = rng_next < rng_end || chunk < n_chunks;
         }
         if (COUNT) wave_iters++;
-        const bool want_leaf = active && L.pend0 != MI_NONE;
-        const bool want_node = active && L.pend0 == MI_NONE && L.cur != MI_DONE;
+        const bool want_leaf = active && L.cur < 0;
+        const bool want_node = active && L.cur >= 0 && L.cur != MI_DONE;
         const int nl = __popcll(__ballot(want_leaf)), nn = __popcll(__ballot(want_node));
         if (nl > 0 && (nl >= leaf_min || nn == 0)) {
             if (want_leaf) {
                 if (COUNT) n_leaves++;
-                leaf_phase(sc, L);
-                if (ANY && L.h.slot >= 0) { L.cur = MI_DONE; L.pend0 = L.pend1 = MI_NONE; } // first accepted hit ends the query
+                leaf_phase(sc, L, stack, my_ovf, ovf_stride);
+                if (ANY && L.h.slot >= 0) { L.cur = MI_DONE; L.sp = 0; } // first accepted hit ends the query
             }
         } else if (want_node) {
             if (COUNT) {
                 n_nodes++;
                 ray_steps++;
 #ifdef MI_DEPTH_HISTOGRAM // visits per tree level (slow: contended atomics); used once to size an LDS treelet
-                int depth = __float_as_int(sc.nodes[4 * (size_t)L.cur + 3].z);
+                int depth = __float_as_int(sc.nodes[8 * (size_t)L.cur + 7].x);
                 atomicAdd(&work_stats[8 + (depth < 40 ? depth : 39)], 1ull);
 #endif
             }
             node_phase(sc, L, stack, my_ovf, ovf_stride);
         }
-        if (active && L.cur == MI_DONE && L.pend0 == MI_NONE) {
+        if (active && L.cur == MI_DONE) {
             hits[slot] = make_float4(L.h.t, __int_as_float(L.h.slot), L.h.u, L.h.v);
             active = false;
             if (COUNT) { max_ray_steps = max(max_ray_steps, ray_steps); ray_steps = 0; }
@@ -869,7 +891,7 @@ k_tail(DevScene sc, ShardGeom g, uint32_t pix0, uint32_t npix, int level0, int d
     int level = level0;
     float4 T = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     Lane L;
-    L.cur = MI_DONE; L.sp = 0; L.pend0 = L.pend1 = MI_NONE; L.exact = false;
+    L.cur = MI_DONE; L.sp = 0; L.exact = false;
     L.h = Hit{MI_NO_HIT, 0.0f, 0.0f, -1};
     L.o = L.d = L.inv = L.noi = mk3(0, 0, 0);
     unsigned long long act = 0ull;
@@ -898,9 +920,9 @@ k_tail(DevScene sc, ShardGeom g, uint32_t pix0, uint32_t npix, int level0, int d
             }
             more = rng_next < rng_end || chunk < n_chunks;
         }
-        const bool want_leaf = active && L.pend0 != MI_NONE;
-        const bool want_node = active && L.pend0 == MI_NONE && L.cur != MI_DONE;
-        const bool want_shade = active && L.pend0 == MI_NONE && L.cur == MI_DONE;
+        const bool want_leaf = active && L.cur < 0;
+        const bool want_node = active && L.cur >= 0 && L.cur != MI_DONE;
+        const bool want_shade = active && L.cur == MI_DONE;
         const int nl = __popcll(__ballot(want_leaf)), nn = __popcll(__ballot(want_node)), ns = __popcll(__ballot(want_shade));
         if (ns > 0 && (ns >= shade_min || (nl == 0 && nn == 0))) {
             bool cont = false;
@@ -923,7 +945,7 @@ k_tail(DevScene sc, ShardGeom g, uint32_t pix0, uint32_t npix, int level0, int d
             }
             n_extra += (uint32_t)__popcll(__ballot(cont));
         } else if (nl > 0 && (nl >= leaf_min || nn == 0)) {
-            if (want_leaf) leaf_phase(sc, L);
+            if (want_leaf) leaf_phase(sc, L, stack, my_ovf, ovf_stride);
         } else if (want_node) {
             node_phase(sc, L, stack, my_ovf, ovf_stride);
         }

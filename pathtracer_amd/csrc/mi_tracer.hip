@@ -59,8 +59,9 @@ struct mi_ctx {
     hipStream_t stream = nullptr;
     bool has_scene = false;
     DevScene sc{};
-    uint32_t n_nodes = 0;
-    DevBuf nodes, tri, tri_normal, tri_mat, tri_has_vmat, sph, sph_mat, mats, prim_id, cube;
+    uint32_t n_nodes = 0;   // of the binary tree kept in `nodes` (download, quality); the kernels walk `nodes4`
+    int32_t root_ref2 = ~0;
+    DevBuf nodes, nodes4, tri, tri_normal, tri_mat, tri_has_vmat, sph, sph_mat, mats, prim_id, cube;
     // per-batch path state (sized by slot capacity / depth): two ray streams (level k reads
     // stream k&1 and writes stream (k+1)&1), hits by stream position, history and path value by slot
     DevBuf ray_o[2], ray_d[2], thr[2], hits, path_out, hist, counters, ovf, totals;
@@ -134,7 +135,7 @@ MI_API void mi_ctx_destroy(mi_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    DevBuf *all[] = {&c->nodes, &c->tri, &c->tri_normal, &c->tri_mat, &c->tri_has_vmat, &c->sph, &c->sph_mat, &c->mats,
+    DevBuf *all[] = {&c->nodes, &c->nodes4, &c->tri, &c->tri_normal, &c->tri_mat, &c->tri_has_vmat, &c->sph, &c->sph_mat, &c->mats,
                      &c->prim_id, &c->cube, &c->ray_o[0], &c->ray_o[1], &c->ray_d[0], &c->ray_d[1], &c->thr[0], &c->thr[1], &c->hits,
                      &c->path_out, &c->hist, &c->counters, &c->ovf, &c->totals, &c->out_mean, &c->out_rgba8,
                      &c->out_rgb8, &c->out_mean_frame, &c->probe_i, &c->probe_t, &c->probe_n};
@@ -185,7 +186,7 @@ static mi_status validate_scene(const mi_scene_soa *s) {
     while (!st.empty()) {
         auto [ref, depth] = st.back();
         st.pop_back();
-        if (depth > MI_MAX_STACK) return fail(MI_ERR_INVALID, "scene: BVH deeper than %d", MI_MAX_STACK);
+        if (depth > MI_MAX_DEPTH) return fail(MI_ERR_INVALID, "scene: BVH deeper than %d", MI_MAX_DEPTH);
         if (seen_node[ref]++) return fail(MI_ERR_INVALID, "scene: node %d referenced twice", ref);
         for (int c = 0; c < 2; c++) {
             int32_t ch;
@@ -210,6 +211,61 @@ static mi_status get_events(mi_ctx *c, size_t n) {
         c->ev.push_back(e);
     }
     return MI_OK;
+}
+
+// The kernels walk a 4-wide tree collapsed from the caller's binary one: a node's seats are
+// its grandchildren (the children of each interior child) or the child itself when that is a
+// leaf.  128 B per node: lo.x[4], lo.y[4], lo.z[4], hi.x[4], hi.y[4], hi.z[4], refs[4], pad.
+// Refs: >= 0 index of a 4-wide node, < 0 leaf ~slot, MI_DONE empty seat.  `nodes2` has been
+// validated (validate_scene) or was built by this library.  Returns the root ref.
+static int32_t collapse_bvh4(const float *nodes2, int32_t root2, std::vector<float> &out) {
+    out.clear();
+    if (root2 < 0) return root2; // a single primitive: no node at all
+    struct Todo { int32_t n2; size_t n4; };
+    std::vector<Todo> todo;
+    auto new_node = [&](int32_t n2) {
+        size_t idx = out.size() / 32;
+        out.resize(out.size() + 32, 0.0f);
+        todo.push_back({n2, idx});
+        return (int32_t)idx;
+    };
+    const int32_t root4 = new_node(root2);
+    while (!todo.empty()) {
+        const Todo t = todo.back();
+        todo.pop_back();
+        float box[4][6];
+        int32_t ref[4];
+        int n = 0;
+        auto child_of = [&](const float *nd, int c, float *b, int32_t &r) {
+            memcpy(b, nd + 6 * c, 24);
+            memcpy(&r, nd + 12 + c, 4);
+        };
+        const float *nd = nodes2 + 16 * (size_t)t.n2;
+        for (int c = 0; c < 2; c++) {
+            float b[6];
+            int32_t r;
+            child_of(nd, c, b, r);
+            if (r < 0) {
+                memcpy(box[n], b, 24);
+                ref[n++] = r;
+            } else {
+                const float *ch = nodes2 + 16 * (size_t)r;
+                for (int g = 0; g < 2; g++) child_of(ch, g, box[n], ref[n]), n++;
+            }
+        }
+        int32_t out_ref[4];
+        for (int k = 0; k < 4; k++) out_ref[k] = MI_DONE;
+        for (int k = 0; k < n; k++) out_ref[k] = ref[k] < 0 ? ref[k] : new_node(ref[k]); // may reallocate `out`
+        float *o = out.data() + 32 * t.n4;
+        for (int k = 0; k < 4; k++) {
+            for (int a = 0; a < 3; a++) {
+                o[4 * a + k] = k < n ? box[k][a] : 0.0f;
+                o[12 + 4 * a + k] = k < n ? box[k][3 + a] : 0.0f;
+            }
+            memcpy(o + 24 + k, &out_ref[k], 4);
+        }
+    }
+    return root4;
 }
 
 // Copies primitives, materials, ids and camera (everything but the nodes) to the device.
@@ -254,6 +310,17 @@ static mi_status upload_prims(mi_ctx *c, const mi_scene_soa *s) {
     return MI_OK;
 }
 
+// Collapses the binary tree (host copy) into the 4-wide tree the kernels walk and uploads it.
+static mi_status install_bvh4(mi_ctx *c, const float *nodes2, int32_t root2) {
+    std::vector<float> n4;
+    const int32_t root4 = collapse_bvh4(nodes2, root2, n4);
+    HIPCHK(c->nodes4.ensure(std::max<size_t>(n4.size() * 4, 16)));
+    if (!n4.empty()) HIPCHK(hipMemcpy(c->nodes4.p, n4.data(), n4.size() * 4, hipMemcpyHostToDevice));
+    c->sc.nodes = c->nodes4.as<float4>();
+    c->sc.root_ref = root4;
+    return MI_OK;
+}
+
 MI_API mi_status mi_scene_upload(mi_ctx *c, const mi_scene_soa *s) {
     if (!c || !s) return fail(MI_ERR_INVALID, "mi_scene_upload: NULL argument");
     c->has_scene = false; // a rejected or failed upload leaves the context without a scene
@@ -264,9 +331,10 @@ MI_API mi_status mi_scene_upload(mi_ctx *c, const mi_scene_soa *s) {
     if (s->n_nodes) HIPCHK(hipMemcpy(c->nodes.p, s->nodes, (size_t)s->n_nodes * 64, hipMemcpyHostToDevice));
     mi_status us = upload_prims(c, s);
     if (us != MI_OK) return us;
-    c->sc.nodes = c->nodes.as<float4>();
-    c->sc.root_ref = s->root_ref;
+    c->root_ref2 = s->root_ref;
     c->n_nodes = s->n_nodes;
+    mi_status cs = install_bvh4(c, s->nodes, (uint64_t)s->n_tri + s->n_sph > 0 ? s->root_ref : ~0);
+    if (cs != MI_OK) return cs;
     c->has_scene = true;
     return MI_OK;
 }
@@ -284,7 +352,7 @@ static mi_status resident_sah_cost(mi_ctx *c, double *out) {
     double sum = 0;
     float root[16];
     hipError_t e = hipMemcpyAsync(&sum, acc.p, 8, hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(root, (const char *)c->nodes.p + (size_t)c->sc.root_ref * 64, 64, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(root, (const char *)c->nodes.p + (size_t)c->root_ref2 * 64, 64, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     acc.release();
     HIPCHK(e);
@@ -307,7 +375,7 @@ MI_API mi_status mi_scene_download_nodes(mi_ctx *c, float *nodes_out, uint32_t c
     if (!c || !n_nodes_out || !root_ref_out) return fail(MI_ERR_INVALID, "mi_scene_download_nodes: NULL argument");
     if (!c->has_scene) return fail(MI_ERR_NO_SCENE, "mi_scene_download_nodes: no scene uploaded");
     *n_nodes_out = c->n_nodes;
-    *root_ref_out = c->sc.root_ref;
+    *root_ref_out = c->root_ref2;
     if (!nodes_out) return MI_OK; // size query
     if (capacity_nodes < c->n_nodes) return fail(MI_ERR_INVALID, "mi_scene_download_nodes: room for %u nodes, tree has %u", capacity_nodes, c->n_nodes);
     HIPCHK(hipSetDevice(c->device));
@@ -334,8 +402,9 @@ MI_API mi_status mi_scene_upload_build(mi_ctx *c, const mi_scene_soa *s, const f
     c->n_nodes = 0;
     if (n <= 1) { // no interior node: bvh.cu:174-183
         HIPCHK(c->nodes.ensure(16));
-        c->sc.nodes = c->nodes.as<float4>();
-        c->sc.root_ref = ~0;
+        c->root_ref2 = ~0;
+        mi_status cs = install_bvh4(c, nullptr, ~0);
+        if (cs != MI_OK) return cs;
         c->has_scene = true;
         return MI_OK;
     }
@@ -401,7 +470,7 @@ MI_API mi_status mi_scene_upload_build(mi_ctx *c, const mi_scene_soa *s, const f
         HIPCHK(hipStreamSynchronize(st));
         float ms = 0;
         HIPCHK(hipEventElapsedTime(&ms, e0, e1));
-        if (h_root > MI_MAX_STACK) return fail(MI_ERR_INVALID, "device-built BVH is %d levels deep (limit %d)", h_root, MI_MAX_STACK);
+        if (h_root > MI_MAX_DEPTH) return fail(MI_ERR_INVALID, "device-built BVH is %d levels deep (limit %d)", h_root, MI_MAX_DEPTH);
         if (stats) {
             const double a = 2.0 * (dx * dy + dy * dz + dz * dx);
             stats->ms_build = ms;
@@ -414,9 +483,14 @@ MI_API mi_status mi_scene_upload_build(mi_ctx *c, const mi_scene_soa *s, const f
     rs = body();
     for (DevBuf *b : tmp) b->release();
     if (rs != MI_OK) return rs;
-    c->sc.nodes = c->nodes.as<float4>();
-    c->sc.root_ref = 0; // Karras: interior node 0 is the root
+    c->root_ref2 = 0; // Karras: interior node 0 is the root
     c->n_nodes = n - 1;
+    // the kernels walk the 4-wide collapse of it (done on the host for now: one copy of the
+    // binary nodes back and one of the 4-wide nodes up, outside stats->ms_build)
+    std::vector<float> n2((size_t)(n - 1) * 16);
+    HIPCHK(hipMemcpy(n2.data(), c->nodes.p, n2.size() * 4, hipMemcpyDeviceToHost));
+    mi_status cs = install_bvh4(c, n2.data(), 0);
+    if (cs != MI_OK) return cs;
     c->has_scene = true;
     return MI_OK;
 }
