@@ -206,3 +206,49 @@ k_nodes_area(uint32_t n_nodes, const float4 *nodes, double *area_sum) {
         if (s != 0) atomicAdd(area_sum, s);
     }
 }
+
+// ---- collapse of the binary tree into the 4-wide tree the traversal kernels walk --------
+// A 4-wide node takes the place of every interior node at EVEN depth; its seats are that
+// node's grandchildren (the children of each interior child) or the child itself when it is
+// a leaf — the same rule as collapse_bvh4() on the host (mi_tracer.hip).
+__global__ void __launch_bounds__(MI_BUILD_BLOCK)
+k_build_even_depth(int n_nodes, const int *parent_node, uint32_t *flag) {
+    const int i = blockIdx.x * MI_BUILD_BLOCK + threadIdx.x;
+    if (i >= n_nodes) return;
+    int d = 0;
+    for (int p = parent_node[i]; p >= 0; p = parent_node[p]) d++; // ends at the root (parent -1)
+    flag[i] = (d & 1) ? 0u : 1u;
+}
+
+__global__ void __launch_bounds__(MI_BUILD_BLOCK)
+k_build_emit4(int n_nodes, const float4 *nodes2, const uint32_t *flag, const uint32_t *index4, float *nodes4, int empty_ref) {
+    const int i = blockIdx.x * MI_BUILD_BLOCK + threadIdx.x;
+    if (i >= n_nodes || !flag[i]) return;
+    float box[4][6];
+    int ref[4];
+    int n = 0;
+    const float *nd = (const float *)(nodes2 + 4 * (size_t)i);
+    for (int c = 0; c < 2; c++) {
+        const int r = __float_as_int(nd[12 + c]);
+        if (r < 0) {
+            for (int k = 0; k < 6; k++) box[n][k] = nd[6 * c + k];
+            ref[n++] = r;
+        } else {
+            const float *ch = (const float *)(nodes2 + 4 * (size_t)r);
+            for (int g = 0; g < 2; g++) {
+                for (int k = 0; k < 6; k++) box[n][k] = ch[6 * g + k];
+                const int rr = __float_as_int(ch[12 + g]);
+                ref[n++] = rr < 0 ? rr : (int)index4[rr];
+            }
+        }
+    }
+    float *o = nodes4 + 32 * (size_t)index4[i];
+    for (int k = 0; k < 4; k++) {
+        for (int a = 0; a < 3; a++) {
+            o[4 * a + k] = k < n ? box[k][a] : 0.0f;
+            o[12 + 4 * a + k] = k < n ? box[k][3 + a] : 0.0f;
+        }
+        o[24 + k] = __int_as_float(k < n ? ref[k] : empty_ref);
+        o[28 + k] = 0.0f;
+    }
+}

@@ -433,7 +433,9 @@ MI_API mi_status mi_scene_upload_build(mi_ctx *c, const mi_scene_soa *s, const f
         size_t cub_bytes = 0;
         HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, cub_bytes, keys_a.as<uint64_t>(), keys_b.as<uint64_t>(), vals_a.as<uint32_t>(),
                                                   vals_b.as<uint32_t>(), (int)n, 0, 62, st));
-        HIPCHK(cub_tmp.ensure(std::max<size_t>(cub_bytes, 16)));
+        size_t scan_bytes = 0; // the prefix sum of the 4-wide collapse shares the scratch
+        HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, flags.as<uint32_t>(), vals_a.as<uint32_t>(), (int)(n - 1), st));
+        HIPCHK(cub_tmp.ensure(std::max<size_t>(std::max(cub_bytes, scan_bytes), 16)));
         mi_status evs = get_events(c, 2); // the context's first two events bracket the build
         if (evs != MI_OK) return evs;
         hipEvent_t e0 = c->ev[0], e1 = c->ev[1];
@@ -461,6 +463,13 @@ MI_API mi_status mi_scene_upload_build(mi_ctx *c, const mi_scene_soa *s, const f
         const float pad = 1e-5f * (float)std::sqrt(dx * dx + dy * dy + dz * dz) + 1e-30f; // as the host flattener
         hipLaunchKernelGGL(k_build_emit, grid, block, 0, st, (int)n, vals_b.as<uint32_t>(), pb.as<BuildBox>(), children.as<int2>(), nb.as<BuildBox>(), pad,
                            c->nodes.as<float4>(), area.as<double>());
+        // 4-wide collapse on the device: even-depth flags, prefix sum -> new indices, emit
+        const dim3 ngrid((n - 1 + MI_BUILD_BLOCK - 1) / MI_BUILD_BLOCK);
+        hipLaunchKernelGGL(k_build_even_depth, ngrid, block, 0, st, (int)(n - 1), par_n.as<int>(), flags.as<uint32_t>());
+        HIPCHK(hipcub::DeviceScan::ExclusiveSum(cub_tmp.p, scan_bytes, flags.as<uint32_t>(), vals_a.as<uint32_t>(), (int)(n - 1), st));
+        HIPCHK(c->nodes4.ensure((size_t)(n - 1) * 128)); // upper bound: every binary node survives
+        hipLaunchKernelGGL(k_build_emit4, ngrid, block, 0, st, (int)(n - 1), c->nodes.as<float4>(), flags.as<uint32_t>(), vals_a.as<uint32_t>(),
+                           c->nodes4.as<float>(), (int)MI_DONE);
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(e1, st));
         int h_root = 0;
@@ -485,12 +494,8 @@ MI_API mi_status mi_scene_upload_build(mi_ctx *c, const mi_scene_soa *s, const f
     if (rs != MI_OK) return rs;
     c->root_ref2 = 0; // Karras: interior node 0 is the root
     c->n_nodes = n - 1;
-    // the kernels walk the 4-wide collapse of it (done on the host for now: one copy of the
-    // binary nodes back and one of the 4-wide nodes up, outside stats->ms_build)
-    std::vector<float> n2((size_t)(n - 1) * 16);
-    HIPCHK(hipMemcpy(n2.data(), c->nodes.p, n2.size() * 4, hipMemcpyDeviceToHost));
-    mi_status cs = install_bvh4(c, n2.data(), 0);
-    if (cs != MI_OK) return cs;
+    c->sc.nodes = c->nodes4.as<float4>(); // collapsed on the device above; the root keeps index 0
+    c->sc.root_ref = 0;
     c->has_scene = true;
     return MI_OK;
 }
