@@ -74,16 +74,37 @@ def main():
     stride = P.shard_pixels(p0)  # rank 0 owns the most tiles
     rgba8 = torch.zeros(stride * 4, dtype=torch.uint8, device=dev)
     gathered = torch.zeros(world * stride * 4, dtype=torch.uint8, device=dev) if (world > 1 and rank == 0) else None
+    frame = torch.zeros(w * h * 3, dtype=torch.uint8, device=dev) if (world > 1 and rank == 0) else None  # assembled frame stays in HBM, like N=1
     stream = torch.cuda.current_stream().cuda_stream
+
+    # Exchange step: RGBA8 tiles of every rank -> rank 0.  dist.gather (grouped send/recv in RCCL) moves
+    # only what rank 0 needs; should the backend refuse it, all ranks fall back together to an all-gather.
+    use_gather = True
+    if world > 1:
+        ok = torch.ones(1, device=dev)
+        try:
+            dist.gather(rgba8, list(gathered.view(world, -1).unbind(0)) if rank == 0 else None, dst=0)
+            torch.cuda.synchronize()
+        except Exception as e:  # noqa: BLE001
+            print(f"[bench] rank {rank}: dist.gather unavailable ({e}); using all_gather_into_tensor", file=sys.stderr)
+            ok.zero_()
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        use_gather = bool(ok.item())
+        if not use_gather and gathered is None:
+            gathered = torch.zeros(world * stride * 4, dtype=torch.uint8, device=dev)
 
     def step():
         st = ctx.render_device(params, None, rgba8.data_ptr(), stream)
         img = None
         if world > 1:
-            dist.gather(rgba8, list(gathered.view(world, -1).unbind(0)) if rank == 0 else None, dst=0)
+            if use_gather:
+                dist.gather(rgba8, list(gathered.view(world, -1).unbind(0)) if rank == 0 else None, dst=0)
+            else:
+                dist.all_gather_into_tensor(gathered, rgba8)
             if rank == 0:
                 torch.cuda.current_stream().synchronize()
-                img = ctx.assemble_rgb8(params, gathered.data_ptr(), stride)
+                ctx.assemble_rgb8_device(params, gathered.data_ptr(), stride, frame.data_ptr(), stream)
+                img = frame
         return st, img
 
     def fence():

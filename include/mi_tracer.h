@@ -209,6 +209,13 @@ mi_status mi_assemble_rgb8(mi_ctx *ctx, const mi_render_params *params,
                            const void *d_gathered, int64_t shard_stride_pixels,
                            uint8_t *rgb8_out);
 
+/* Same scatter with the frame left in DEVICE memory (d_rgb8_out: uint8[width*height*3]),
+ * so that a multi-GPU render ends like a single-GPU mi_render_device: everything in HBM.
+ * Enqueued on `stream` (NULL = the context's stream) and synchronised before returning. */
+mi_status mi_assemble_rgb8_device(mi_ctx *ctx, const mi_render_params *params,
+                                  const void *d_gathered, int64_t shard_stride_pixels,
+                                  void *d_rgb8_out, void *stream);
+
 /* Primary-ray closest hit only (parity probe; the reference has no such entry —
  * it corresponds to Camera::rayThrough (camera.cu:6-16) + Scene::intersect
  * (scene.h:70-72) per sample of CpuTracer::tracePixel (CpuTracer.cu:99-109)).

@@ -73,7 +73,7 @@ class BuildStats(C.Structure):
 MI_SYMBOLS = [
     "mi_ctx_create", "mi_ctx_destroy", "mi_scene_upload", "mi_scene_upload_build", "mi_scene_quality",
     "mi_scene_download_nodes", "mi_cubemap_upload", "mi_render", "mi_render_device", "mi_shard_pixels",
-    "mi_assemble_rgb8", "mi_trace_primary", "mi_trace_rays", "mi_occluded_rays", "mi_last_error", "mi_abi_version",
+    "mi_assemble_rgb8", "mi_assemble_rgb8_device", "mi_trace_primary", "mi_trace_rays", "mi_occluded_rays", "mi_last_error", "mi_abi_version",
 ]
 
 
@@ -103,6 +103,8 @@ mi.mi_assemble_rgb8.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.c_void_p,
 mi.mi_assemble_rgb8.restype = C.c_int
 mi.mi_trace_primary.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
 mi.mi_trace_primary.restype = C.c_int
+mi.mi_assemble_rgb8_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+mi.mi_assemble_rgb8_device.restype = C.c_int
 mi.mi_trace_rays.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
 mi.mi_trace_rays.restype = C.c_int
 mi.mi_occluded_rays.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]

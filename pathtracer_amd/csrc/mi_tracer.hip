@@ -89,7 +89,7 @@ static const int kCounterWords = (kMaxLevels + 1) * kLevelWords + MI_CNT_STRIDE;
 
 static int extend_grid(const mi_ctx *c) { return c->n_cu * c->extend_wg_per_cu; }
 
-MI_API int mi_abi_version(void) { return 6; }
+MI_API int mi_abi_version(void) { return 7; }
 MI_API const char *mi_last_error(void) { return g_err.c_str(); }
 
 MI_API mi_status mi_ctx_create(int device_id, mi_ctx **out) {
@@ -753,25 +753,42 @@ MI_API mi_status mi_render(mi_ctx *c, const mi_render_params *p, float *rgba_mea
     return MI_OK;
 }
 
-MI_API mi_status mi_assemble_rgb8(mi_ctx *c, const mi_render_params *p, const void *d_gathered, int64_t shard_stride_pixels, uint8_t *rgb8_out) {
-    if (!c || !d_gathered || !rgb8_out) return fail(MI_ERR_INVALID, "mi_assemble_rgb8: NULL argument");
+static mi_status assemble_common(mi_ctx *c, const mi_render_params *p, const void *d_gathered, int64_t shard_stride_pixels, uint8_t *d_out,
+                                  hipStream_t st) {
     ShardGeom g;
     mi_status gs = make_geom(p, g);
     if (gs != MI_OK) return gs;
-    HIPCHK(hipSetDevice(c->device));
     ShardGeom g0 = g;
     g0.rank = 0;
     const int64_t sp = shard_pixels(g0); // rank 0 owns the most tiles
     if (shard_stride_pixels < sp) return fail(MI_ERR_INVALID, "shard stride %lld < shard pixels %lld", (long long)shard_stride_pixels, (long long)sp);
-    const size_t bytes = (size_t)g.width * g.height * 3;
-    HIPCHK(c->out_rgb8.ensure(bytes));
-    HIPCHK(hipMemsetAsync(c->out_rgb8.p, 0, bytes, c->stream));
-    const int64_t total = sp * g.count;
-    hipLaunchKernelGGL(k_assemble, dim3((unsigned)((total + MI_BLOCK - 1) / MI_BLOCK)), dim3(MI_BLOCK), 0, c->stream, g, (const uchar4 *)d_gathered,
-                       shard_stride_pixels, sp, c->out_rgb8.as<uint8_t>());
+    const int64_t total = sp * g.count; // every pixel of the frame belongs to exactly one shard: no clearing needed
+    hipLaunchKernelGGL(k_assemble, dim3((unsigned)((total + MI_BLOCK - 1) / MI_BLOCK)), dim3(MI_BLOCK), 0, st, g, (const uchar4 *)d_gathered,
+                       shard_stride_pixels, sp, d_out);
     HIPCHK(hipGetLastError());
+    return MI_OK;
+}
+
+MI_API mi_status mi_assemble_rgb8(mi_ctx *c, const mi_render_params *p, const void *d_gathered, int64_t shard_stride_pixels, uint8_t *rgb8_out) {
+    if (!c || !p || !d_gathered || !rgb8_out) return fail(MI_ERR_INVALID, "mi_assemble_rgb8: NULL argument");
+    HIPCHK(hipSetDevice(c->device));
+    const size_t bytes = (size_t)p->width * p->height * 3;
+    HIPCHK(c->out_rgb8.ensure(std::max<size_t>(bytes, 16)));
+    mi_status as = assemble_common(c, p, d_gathered, shard_stride_pixels, c->out_rgb8.as<uint8_t>(), c->stream);
+    if (as != MI_OK) return as;
     HIPCHK(hipMemcpyAsync(rgb8_out, c->out_rgb8.p, bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    return MI_OK;
+}
+
+MI_API mi_status mi_assemble_rgb8_device(mi_ctx *c, const mi_render_params *p, const void *d_gathered, int64_t shard_stride_pixels,
+                                         void *d_rgb8_out, void *stream) {
+    if (!c || !p || !d_gathered || !d_rgb8_out) return fail(MI_ERR_INVALID, "mi_assemble_rgb8_device: NULL argument");
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    mi_status as = assemble_common(c, p, d_gathered, shard_stride_pixels, (uint8_t *)d_rgb8_out, st);
+    if (as != MI_OK) return as;
+    HIPCHK(hipStreamSynchronize(st));
     return MI_OK;
 }
 

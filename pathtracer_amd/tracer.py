@@ -93,6 +93,9 @@ class Context:
         N.check(N.mi.mi_assemble_rgb8(self._h, C.byref(params), d_gathered_ptr, shard_stride_pixels, rgb.ctypes.data))
         return rgb
 
+    def assemble_rgb8_device(self, params, d_gathered_ptr, shard_stride_pixels, d_rgb8_ptr, stream=None):
+        N.check(N.mi.mi_assemble_rgb8_device(self._h, C.byref(params), d_gathered_ptr, shard_stride_pixels, d_rgb8_ptr, stream))
+
     def trace_primary(self, width, height, samples, want_normals=True):
         n = width * height * samples * samples
         ids = np.empty(n, np.int32)

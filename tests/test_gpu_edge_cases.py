@@ -93,6 +93,10 @@ def test_device_outputs_gather_and_assemble(ctx, scenes_small):
     torch.cuda.synchronize()
     frame = ctx.assemble_rgb8(P.Context.params(w, h, 1, 4, shard=(0, count)), gathered.data_ptr(), stride)
     assert np.array_equal(frame, full)
+    dframe = torch.full((h * w * 3,), 77, dtype=torch.uint8, device="cuda")   # every byte must be overwritten
+    ctx.assemble_rgb8_device(P.Context.params(w, h, 1, 4, shard=(0, count)), gathered.data_ptr(), stride, dframe.data_ptr(),
+                             torch.cuda.current_stream().cuda_stream)
+    assert np.array_equal(dframe.cpu().numpy().reshape(h, w, 3), full)
     # the documented shard-local layout matches the host-side mirror in sharding.py
     local = gathered.cpu().numpy().reshape(count, stride, 4)
     assert np.array_equal(sharding.assemble([local[r, :, :3] for r in range(count)], w, h), full)
