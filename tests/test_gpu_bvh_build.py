@@ -135,3 +135,18 @@ def test_device_build_quality_and_time_on_the_bench_scene(ctx):
     sah = ctx.scene_quality()
     print(f"\nblob82k: LBVH {st.ms_build:.2f} ms on the device, depth {st.depth}, SAH cost {lbvh:.1f} vs host binned-SAH {sah:.1f}")
     assert st.depth <= 64 and sah <= lbvh < 3.0 * sah
+
+
+def test_device_and_host_trees_render_the_same_image_on_a_larger_mesh(ctx):
+    """20k triangles, 4-wide collapse on the device vs on the host: same bytes, same ray count."""
+    sc = scenes.blob_scene(5)
+    w, h = sc.image_size(320)
+    p = P.Context.params(w, h, 2, 5, seed=17)
+    ctx.upload(sc)
+    mean_h, rgb_h, st_h = ctx.render(p)
+    ids_h, t_h, _ = ctx.trace_primary(w, h, 1, want_normals=False)
+    ctx.upload_build(sc)
+    mean_d, rgb_d, st_d = ctx.render(p)
+    ids_d, t_d, _ = ctx.trace_primary(w, h, 1, want_normals=False)
+    assert st_h.rays_cast == st_d.rays_cast and same(mean_h, mean_d) and np.array_equal(rgb_h, rgb_d)
+    assert np.array_equal(ids_h, ids_d) and same(t_h, t_d)
