@@ -39,6 +39,9 @@ def main():
     ap.add_argument("--workload", default="C3-blob82k-1080p-16spp", choices=sorted(WORKLOADS))
     ap.add_argument("--bvh", default="host", choices=["host", "device"],
                     help="host: binned-SAH tree built by libpt_host (default); device: LBVH built by mi_scene_upload_build")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo: rehearsal of the N>1 path with several ranks on ONE GPU (tiles staged through the host); never a result")
+    ap.add_argument("--check", action="store_true", help="N>1: rank 0 also renders the whole frame alone and compares the assembled frame byte for byte")
     ap.add_argument("--batch-paths", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -55,10 +58,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if args.backend == "gloo":
+        local_rank = 0  # rehearsal: every rank on the one GPU of the box
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     build, width, samples, depth = WORKLOADS[args.workload]
     scene = build(S)
@@ -80,7 +88,10 @@ def main():
     # Exchange step: RGBA8 tiles of every rank -> rank 0.  dist.gather (grouped send/recv in RCCL) moves
     # only what rank 0 needs; should the backend refuse it, all ranks fall back together to an all-gather.
     use_gather = True
-    if world > 1:
+    if world > 1 and args.backend == "gloo":
+        host_local = torch.zeros(stride * 4, dtype=torch.uint8)
+        host_all = [torch.zeros(stride * 4, dtype=torch.uint8) for _ in range(world)] if rank == 0 else None
+    if world > 1 and args.backend == "nccl":
         ok = torch.ones(1, device=dev)
         try:
             dist.gather(rgba8, list(gathered.view(world, -1).unbind(0)) if rank == 0 else None, dst=0)
@@ -97,7 +108,12 @@ def main():
         st = ctx.render_device(params, None, rgba8.data_ptr(), stream)
         img = None
         if world > 1:
-            if use_gather:
+            if args.backend == "gloo":
+                host_local.copy_(rgba8)
+                dist.gather(host_local, host_all, dst=0)
+                if rank == 0:
+                    gathered.copy_(torch.cat(host_all))
+            elif use_gather:
                 dist.gather(rgba8, list(gathered.view(world, -1).unbind(0)) if rank == 0 else None, dst=0)
             else:
                 dist.all_gather_into_tensor(gathered, rgba8)
@@ -130,7 +146,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
 
-    tot = torch.tensor([float(rays), dt, ms_extend, float(n_ext)], dtype=torch.float64, device=dev)
+    tot = torch.tensor([float(rays), dt, ms_extend, float(n_ext)], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
     if world > 1:
         mx = tot.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
@@ -140,6 +156,13 @@ def main():
     else:
         dt_max, rays_all = dt, float(rays)
 
+    if rank == 0 and world > 1 and args.check:
+        pf = P.Context.params(w, h, samples, depth, seed=0)
+        solo = ctx.render(pf, want_mean=False)[1]
+        same = bool((img.cpu().numpy().reshape(h, w, 3) == solo).all())
+        print(f"[bench] assembled {world}-rank frame == single-rank frame: {same}", file=sys.stderr)
+        if not same:
+            raise SystemExit("assembled frame differs from the single-rank render")
     if rank == 0:
         # Roofline of the dominant kernel (k_extend) — algorithmic bytes of ITS OWN
         # traversal, counted by the instrumented kernel variant outside the timed region.
@@ -174,6 +197,7 @@ def main():
                        "primitives": scene.n_prims,
                        "bvh": "device LBVH" if build else "host binned SAH", "bvh_depth": build.depth if build else scene.bvh_depth,
                        "bvh_sah_cost": sah_cost, "bvh_build_ms": build.ms_build if build else None, "sharding": f"tile32x{world}",
+                       "exchange": None if world == 1 else ("RCCL gather of RGBA8 tiles to rank 0" if args.backend == "nccl" else "REHEARSAL: gloo, all ranks on one GPU"),
                        "rays_per_step": rays_all / args.steps},
             "roofline": {"bound": "hbm", "kernel": "k_extend", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": pmc_traffic(args.workload, world),
