@@ -18,7 +18,7 @@ HOST_HDR = pathtracer_amd/host/scene.h pathtracer_amd/host/tracer.h pathtracer_a
 
 all: $(LIB)/libmi_tracer.so $(LIB)/libpt_host.so $(BIN)/ray oracle/liboracle.so
 
-$(LIB)/libmi_tracer.so: pathtracer_amd/csrc/mi_tracer.hip pathtracer_amd/csrc/mi_kernels.h include/mi_tracer.h
+$(LIB)/libmi_tracer.so: pathtracer_amd/csrc/mi_tracer.hip pathtracer_amd/csrc/mi_kernels.h pathtracer_amd/csrc/mi_bvh_build.h include/mi_tracer.h
 	@mkdir -p $(LIB)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ pathtracer_amd/csrc/mi_tracer.hip
 

@@ -145,12 +145,13 @@ void mi_ctx_destroy(mi_ctx *ctx);
 mi_status mi_scene_upload(mi_ctx *ctx, const mi_scene_soa *scene);
 
 /* Same as mi_scene_upload, but the BVH is BUILT ON THE DEVICE: scene->nodes / n_nodes /
- * root_ref are ignored, primitives stay in the caller's slot order, and tri_verts gives the
- * three vertices of every triangle slot (float[9*n_tri], HOST; the boxes of
+ * root_ref are ignored, and tri_verts gives the three vertices of every triangle slot (float[9*n_tri], HOST; the boxes of
  * geometry.h:13-29 need them — the precomputed uInv/vInv/nInv do not contain them).
  * Replaces the host-side BoundedVolumeHierarchy::construct + flatten (bvh.cu:66-172,
- * 239-369) with an LBVH: Morton codes, one radix sort, Karras topology,
- * bottom-up fit.  The rendered image does not depend on which tree is used (exact-t ties
+ * 239-369) with PLOC (parallel locally-ordered clustering over the Morton
+ * order; MI_TRACER_BUILDER=lbvh in the environment selects a plain Karras LBVH).  The
+ * primitive records are gathered into tree order on the device: the slots the resident tree
+ * refers to are NOT the caller's (mi_scene_download_prim_ids maps them to primitive ids).  The rendered image does not depend on which tree is used (exact-t ties
  * are resolved by primitive id and child boxes are padded, see mi_scene_soa.prim_id), so
  * renders with this tree are bit-identical to renders with an uploaded one.  A tree
  * deeper than 64 levels is rejected (MI_ERR_INVALID).  stats may be NULL. */
@@ -173,6 +174,10 @@ mi_status mi_scene_quality(mi_ctx *ctx, double *sah_cost_out);
  * queries n_nodes / root_ref.  No counterpart in the reference. */
 mi_status mi_scene_download_nodes(mi_ctx *ctx, float *nodes_out, uint32_t capacity_nodes,
                                   uint32_t *n_nodes_out, int32_t *root_ref_out);
+
+/* prim_id of every slot of the resident scene (the caller's array after mi_scene_upload, the
+ * permuted one after mi_scene_upload_build).  No counterpart in the reference. */
+mi_status mi_scene_download_prim_ids(mi_ctx *ctx, int32_t *prim_id_out, uint32_t capacity);
 
 /* Render (this shard of) the image: the whole of GpuTracer::traceImage
  * (GpuTracer.cu:161-189) incl. the host setPixel loop (:186-188, tracer.cu:95-100).

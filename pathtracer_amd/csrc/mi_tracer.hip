@@ -89,7 +89,7 @@ static const int kCounterWords = (kMaxLevels + 1) * kLevelWords + MI_CNT_STRIDE;
 
 static int extend_grid(const mi_ctx *c) { return c->n_cu * c->extend_wg_per_cu; }
 
-MI_API int mi_abi_version(void) { return 7; }
+MI_API int mi_abi_version(void) { return 8; }
 MI_API const char *mi_last_error(void) { return g_err.c_str(); }
 
 MI_API mi_status mi_ctx_create(int device_id, mi_ctx **out) {
@@ -383,6 +383,16 @@ MI_API mi_status mi_scene_download_nodes(mi_ctx *c, float *nodes_out, uint32_t c
     return MI_OK;
 }
 
+MI_API mi_status mi_scene_download_prim_ids(mi_ctx *c, int32_t *prim_id_out, uint32_t capacity) {
+    if (!c || !prim_id_out) return fail(MI_ERR_INVALID, "mi_scene_download_prim_ids: NULL argument");
+    if (!c->has_scene) return fail(MI_ERR_NO_SCENE, "mi_scene_download_prim_ids: no scene uploaded");
+    const uint32_t n = c->sc.n_tri + c->sc.n_sph;
+    if (capacity < n) return fail(MI_ERR_INVALID, "mi_scene_download_prim_ids: room for %u ids, scene has %u primitives", capacity, n);
+    HIPCHK(hipSetDevice(c->device));
+    if (n) HIPCHK(hipMemcpy(prim_id_out, c->prim_id.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return MI_OK;
+}
+
 MI_API mi_status mi_scene_upload_build(mi_ctx *c, const mi_scene_soa *s, const float *tri_verts, mi_build_stats *stats) {
     if (!c || !s) return fail(MI_ERR_INVALID, "mi_scene_upload_build: NULL argument");
     c->has_scene = false;
@@ -410,9 +420,13 @@ MI_API mi_status mi_scene_upload_build(mi_ctx *c, const mi_scene_soa *s, const f
     }
     hipStream_t st = c->stream;
     // build-time scratch, released when the build is done (the build is not a hot path)
-    DevBuf verts, pb, sbox, keys_a, keys_b, vals_a, vals_b, children, par_n, par_l, nb, height, flags, area, cub_tmp;
-    DevBuf *tmp[] = {&verts, &pb, &sbox, &keys_a, &keys_b, &vals_a, &vals_b, &children, &par_n, &par_l, &nb, &height, &flags, &area, &cub_tmp};
+    DevBuf verts, pb, sbox, keys_a, keys_b, vals_a, vals_b, children, par_n, par_l, nb, height, flags, area, cub_tmp, ref_a, ref_t, box_a, box_t, r_tri, r_nrm, r_mat, r_vm, r_sph, r_smat, r_id;
+    DevBuf *tmp[] = {&r_tri, &r_nrm, &r_mat, &r_vm, &r_sph, &r_smat, &r_id, &verts, &pb, &sbox, &keys_a, &keys_b, &vals_a, &vals_b, &children, &par_n, &par_l, &nb, &height, &flags, &area, &cub_tmp, &ref_a, &ref_t, &box_a, &box_t};
     mi_status rs = MI_OK;
+    // MI_TRACER_BUILDER=lbvh selects the plain Karras LBVH; the default is PLOC over the same Morton order
+    const char *builder = getenv("MI_TRACER_BUILDER");
+    const bool use_ploc = !(builder && !strcmp(builder, "lbvh"));
+    int32_t root2 = 0, root4 = 0;
     auto body = [&]() -> mi_status {
         HIPCHK(verts.ensure(std::max<size_t>((size_t)s->n_tri * 36, 16)));
         if (s->n_tri) HIPCHK(hipMemcpyAsync(verts.p, tri_verts, (size_t)s->n_tri * 36, hipMemcpyHostToDevice, st));
@@ -434,7 +448,7 @@ MI_API mi_status mi_scene_upload_build(mi_ctx *c, const mi_scene_soa *s, const f
         HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, cub_bytes, keys_a.as<uint64_t>(), keys_b.as<uint64_t>(), vals_a.as<uint32_t>(),
                                                   vals_b.as<uint32_t>(), (int)n, 0, 62, st));
         size_t scan_bytes = 0; // the prefix sum of the 4-wide collapse shares the scratch
-        HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, flags.as<uint32_t>(), vals_a.as<uint32_t>(), (int)(n - 1), st));
+        HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, flags.as<uint32_t>(), vals_a.as<uint32_t>(), (int)n, st));
         HIPCHK(cub_tmp.ensure(std::max<size_t>(std::max(cub_bytes, scan_bytes), 16)));
         mi_status evs = get_events(c, 2); // the context's first two events bracket the build
         if (evs != MI_OK) return evs;
@@ -452,20 +466,79 @@ MI_API mi_status mi_scene_upload_build(mi_ctx *c, const mi_scene_soa *s, const f
         hipLaunchKernelGGL(k_build_morton, grid, block, 0, st, n, pb.as<BuildBox>(), sbox.as<float>(), keys_a.as<uint64_t>(), vals_a.as<uint32_t>());
         HIPCHK(hipcub::DeviceRadixSort::SortPairs(cub_tmp.p, cub_bytes, keys_a.as<uint64_t>(), keys_b.as<uint64_t>(), vals_a.as<uint32_t>(),
                                                   vals_b.as<uint32_t>(), (int)n, 0, 62, st));
-        hipLaunchKernelGGL(k_build_topology, grid, block, 0, st, (int)n, keys_b.as<uint64_t>(), children.as<int2>(), par_n.as<int>(), par_l.as<int>());
-        hipLaunchKernelGGL(k_build_fit, grid, block, 0, st, (int)n, vals_b.as<uint32_t>(), pb.as<BuildBox>(), children.as<int2>(), par_n.as<int>(),
-                           par_l.as<int>(), nb.as<BuildBox>(), height.as<int>(), flags.as<unsigned int>());
+        // primitives into Morton order (per class), prim_id and boxes along with them
+        {
+            const size_t nt = s->n_tri, ns = s->n_sph;
+            HIPCHK(r_tri.ensure(std::max<size_t>(nt * 64, 16)));
+            HIPCHK(r_nrm.ensure(std::max<size_t>(nt * 16, 16)));
+            HIPCHK(r_mat.ensure(std::max<size_t>(nt * 12, 16)));
+            HIPCHK(r_vm.ensure(std::max<size_t>(nt, 16)));
+            HIPCHK(r_sph.ensure(std::max<size_t>(ns * 16, 16)));
+            HIPCHK(r_smat.ensure(std::max<size_t>(ns * 4, 16)));
+            HIPCHK(r_id.ensure((size_t)n * 4));
+            HIPCHK(nb.ensure((size_t)n * sizeof(BuildBox))); // permuted boxes (nb is free until the fit)
+            hipLaunchKernelGGL(k_build_is_tri, grid, block, 0, st, (int)n, vals_b.as<uint32_t>(), s->n_tri, flags.as<uint32_t>());
+            HIPCHK(hipcub::DeviceScan::ExclusiveSum(cub_tmp.p, scan_bytes, flags.as<uint32_t>(), vals_a.as<uint32_t>(), (int)n, st));
+            const PrimArrays src{c->tri.as<float4>(), c->tri_normal.as<float4>(), c->sph.as<float4>(), c->tri_mat.as<uint32_t>(), c->sph_mat.as<uint32_t>(),
+                                 c->tri_has_vmat.as<uint8_t>(), c->prim_id.as<int32_t>(), pb.as<BuildBox>()};
+            const PrimArrays dst{r_tri.as<float4>(), r_nrm.as<float4>(), r_sph.as<float4>(), r_mat.as<uint32_t>(), r_smat.as<uint32_t>(),
+                                 r_vm.as<uint8_t>(), r_id.as<int32_t>(), nb.as<BuildBox>()};
+            hipLaunchKernelGGL(k_build_permute, grid, block, 0, st, (int)n, s->n_tri, vals_b.as<uint32_t>(), vals_a.as<uint32_t>(), src, dst);
+            HIPCHK(hipGetLastError());
+            std::swap(c->tri, r_tri); std::swap(c->tri_normal, r_nrm); std::swap(c->tri_mat, r_mat); std::swap(c->tri_has_vmat, r_vm);
+            std::swap(c->sph, r_sph); std::swap(c->sph_mat, r_smat); std::swap(c->prim_id, r_id); std::swap(pb, nb);
+            DevScene &d = c->sc;
+            d.tri = c->tri.as<float4>(); d.tri_normal = c->tri_normal.as<float4>(); d.tri_mat = c->tri_mat.as<uint32_t>();
+            d.tri_has_vmat = c->tri_has_vmat.as<uint8_t>(); d.sph = c->sph.as<float4>(); d.sph_mat = c->sph_mat.as<uint32_t>();
+            d.prim_id = c->prim_id.as<int32_t>();
+            HIPCHK(hipMemsetAsync(flags.p, 0, (size_t)n * 4, st)); // the fit's arrival flags start at zero
+        }
         // padding needs the scene diagonal: one small read-back in the middle of the build
         float hb[8];
         HIPCHK(hipMemcpyAsync(hb, sbox.p, 32, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         const double dx = (double)hb[3] - hb[0], dy = (double)hb[4] - hb[1], dz = (double)hb[5] - hb[2];
         const float pad = 1e-5f * (float)std::sqrt(dx * dx + dy * dy + dz * dz) + 1e-30f; // as the host flattener
-        hipLaunchKernelGGL(k_build_emit, grid, block, 0, st, (int)n, vals_b.as<uint32_t>(), pb.as<BuildBox>(), children.as<int2>(), nb.as<BuildBox>(), pad,
-                           c->nodes.as<float4>(), area.as<double>());
-        // 4-wide collapse on the device: even-depth flags, prefix sum -> new indices, emit
         const dim3 ngrid((n - 1 + MI_BUILD_BLOCK - 1) / MI_BUILD_BLOCK);
-        hipLaunchKernelGGL(k_build_even_depth, ngrid, block, 0, st, (int)(n - 1), par_n.as<int>(), flags.as<uint32_t>());
+        if (use_ploc) {
+            // PLOC rounds: nearest neighbour in the window, merge mutual pairs, compact
+            HIPCHK(ref_a.ensure((size_t)n * 4));
+            HIPCHK(ref_t.ensure((size_t)n * 4));
+            HIPCHK(box_a.ensure((size_t)n * sizeof(BuildBox)));
+            HIPCHK(box_t.ensure((size_t)n * sizeof(BuildBox)));
+            HIPCHK(hipMemsetAsync(sbox.as<uint32_t>() + 6, 0, 8, st)); // [6] node counter, [7] cluster count
+            hipLaunchKernelGGL(k_ploc_init, grid, block, 0, st, (int)n, vals_b.as<uint32_t>(), pb.as<BuildBox>(), ref_a.as<int>(), box_a.as<BuildBox>());
+            uint32_t m = n;
+            for (int round = 0; m > 1; round++) {
+                if (round > 4096) return fail(MI_ERR_HIP, "PLOC did not converge");
+                const dim3 mg((m + MI_BUILD_BLOCK - 1) / MI_BUILD_BLOCK);
+                hipLaunchKernelGGL(k_ploc_nearest, mg, block, 0, st, (int)m, box_a.as<BuildBox>(), par_l.as<int>());
+                hipLaunchKernelGGL(k_ploc_merge, mg, block, 0, st, (int)m, par_l.as<int>(), ref_a.as<int>(), box_a.as<BuildBox>(), ref_t.as<int>(),
+                                   box_t.as<BuildBox>(), flags.as<uint32_t>(), sbox.as<uint32_t>() + 6, c->nodes.as<float4>(), par_n.as<int>(), pad);
+                HIPCHK(hipcub::DeviceScan::ExclusiveSum(cub_tmp.p, scan_bytes, flags.as<uint32_t>(), vals_a.as<uint32_t>(), (int)m, st));
+                hipLaunchKernelGGL(k_ploc_compact, mg, block, 0, st, (int)m, flags.as<uint32_t>(), vals_a.as<uint32_t>(), ref_t.as<int>(), box_t.as<BuildBox>(),
+                                   ref_a.as<int>(), box_a.as<BuildBox>(), sbox.as<uint32_t>() + 7);
+                HIPCHK(hipGetLastError());
+                uint32_t m_new = 0;
+                HIPCHK(hipMemcpyAsync(&m_new, sbox.as<uint32_t>() + 7, 4, hipMemcpyDeviceToHost, st));
+                HIPCHK(hipStreamSynchronize(st));
+                if (m_new == 0 || m_new >= m) return fail(MI_ERR_HIP, "PLOC round made no progress (%u -> %u clusters)", m, m_new);
+                m = m_new;
+            }
+            HIPCHK(hipMemcpyAsync(&root2, ref_a.p, 4, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            if (root2 < 0 || (uint32_t)root2 >= n - 1) return fail(MI_ERR_HIP, "PLOC produced a bad root");
+            hipLaunchKernelGGL(k_nodes_area, ngrid, block, 0, st, n - 1, c->nodes.as<float4>(), area.as<double>());
+        } else {
+            hipLaunchKernelGGL(k_build_topology, grid, block, 0, st, (int)n, keys_b.as<uint64_t>(), children.as<int2>(), par_n.as<int>(), par_l.as<int>());
+            hipLaunchKernelGGL(k_build_fit, grid, block, 0, st, (int)n, vals_b.as<uint32_t>(), pb.as<BuildBox>(), children.as<int2>(), par_n.as<int>(),
+                               par_l.as<int>(), nb.as<BuildBox>(), height.as<int>(), flags.as<unsigned int>());
+            hipLaunchKernelGGL(k_build_emit, grid, block, 0, st, (int)n, vals_b.as<uint32_t>(), pb.as<BuildBox>(), children.as<int2>(), nb.as<BuildBox>(), pad,
+                               c->nodes.as<float4>(), area.as<double>());
+            root2 = 0; // Karras: interior node 0 is the root
+        }
+        // 4-wide collapse on the device: even-depth flags (+ tree depth), prefix sum -> new indices, emit
+        hipLaunchKernelGGL(k_build_even_depth, ngrid, block, 0, st, (int)(n - 1), par_n.as<int>(), flags.as<uint32_t>(), height.as<int>());
         HIPCHK(hipcub::DeviceScan::ExclusiveSum(cub_tmp.p, scan_bytes, flags.as<uint32_t>(), vals_a.as<uint32_t>(), (int)(n - 1), st));
         HIPCHK(c->nodes4.ensure((size_t)(n - 1) * 128)); // upper bound: every binary node survives
         hipLaunchKernelGGL(k_build_emit4, ngrid, block, 0, st, (int)(n - 1), c->nodes.as<float4>(), flags.as<uint32_t>(), vals_a.as<uint32_t>(),
@@ -474,14 +547,18 @@ MI_API mi_status mi_scene_upload_build(mi_ctx *c, const mi_scene_soa *s, const f
         HIPCHK(hipEventRecord(e1, st));
         int h_root = 0;
         double area_sum = 0;
+        uint32_t root4u = 0;
         HIPCHK(hipMemcpyAsync(&h_root, height.p, 4, hipMemcpyDeviceToHost, st));
         HIPCHK(hipMemcpyAsync(&area_sum, area.p, 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(&root4u, vals_a.as<uint32_t>() + root2, 4, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
+        root4 = (int32_t)root4u;
         float ms = 0;
         HIPCHK(hipEventElapsedTime(&ms, e0, e1));
         if (h_root > MI_MAX_DEPTH) return fail(MI_ERR_INVALID, "device-built BVH is %d levels deep (limit %d)", h_root, MI_MAX_DEPTH);
         if (stats) {
-            const double a = 2.0 * (dx * dy + dy * dz + dz * dx);
+            double a = 2.0 * (dx * dy + dy * dz + dz * dx);
+            if (use_ploc) { const double px = dx + 2.0 * pad, py = dy + 2.0 * pad, pz = dz + 2.0 * pad; a = 2.0 * (px * py + py * pz + pz * px); } // its boxes are summed padded
             stats->ms_build = ms;
             stats->sah_cost = a > 0 ? 1.0 + area_sum / a : 0.0;
             stats->depth = h_root;
@@ -492,10 +569,10 @@ MI_API mi_status mi_scene_upload_build(mi_ctx *c, const mi_scene_soa *s, const f
     rs = body();
     for (DevBuf *b : tmp) b->release();
     if (rs != MI_OK) return rs;
-    c->root_ref2 = 0; // Karras: interior node 0 is the root
+    c->root_ref2 = root2;
     c->n_nodes = n - 1;
-    c->sc.nodes = c->nodes4.as<float4>(); // collapsed on the device above; the root keeps index 0
-    c->sc.root_ref = 0;
+    c->sc.nodes = c->nodes4.as<float4>(); // collapsed on the device above
+    c->sc.root_ref = root4;
     c->has_scene = true;
     return MI_OK;
 }

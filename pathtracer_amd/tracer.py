@@ -67,6 +67,14 @@ class Context:
         N.check(N.mi.mi_scene_download_nodes(self._h, nodes.ctypes.data if n.value else None, n.value, C.byref(n), C.byref(root)))
         return nodes, root.value
 
+    def download_prim_ids(self):
+        """int32[n_prims]: primitive id of every device slot (permuted by upload_build)."""
+        n = self.scene.n_prims
+        ids = np.zeros(n, np.int32)
+        if n:
+            N.check(N.mi.mi_scene_download_prim_ids(self._h, ids.ctypes.data, n))
+        return ids
+
     @staticmethod
     def params(width, height, samples, depth, seed=0, tile=(0, 0), shard=(0, 1), batch_paths=0, count_work=False):
         return N.RenderParams(width, height, samples, depth, seed, tile[0], tile[1], shard[0], shard[1], batch_paths,

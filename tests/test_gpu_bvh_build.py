@@ -32,6 +32,21 @@ def prim_bounds(sc):
     return np.concatenate(lo), np.concatenate(hi)
 
 
+def device_bounds(ctx, sc):
+    """Bounds per DEVICE slot: upload_build gathers the primitives into tree order."""
+    lo, hi = prim_bounds(sc)
+    host_ids = sc.array("prim_id", (sc.n_prims,), np.int32)
+    host_slot_of_id = np.argsort(host_ids)
+    assert np.array_equal(host_ids[host_slot_of_id], np.arange(sc.n_prims))
+    dev_ids = ctx.download_prim_ids()
+    assert sorted(dev_ids.tolist()) == list(range(sc.n_prims))
+    # triangles keep the slot range [0, n_tri), spheres the one behind it
+    nt = sc.soa.contents.n_tri
+    assert np.all(host_slot_of_id[dev_ids[:nt]] < nt) and np.all(host_slot_of_id[dev_ids[nt:]] >= nt)
+    m = host_slot_of_id[dev_ids]                    # device slot -> host slot
+    return lo[m], hi[m], m
+
+
 def check_tree(nodes, root, lo, hi):
     """Every primitive in exactly one leaf, every child box encloses its subtree; returns depth."""
     n_prim = len(lo)
@@ -70,8 +85,8 @@ def test_device_built_tree_is_valid_and_renders_identically(ctx, scenes_small, n
     sc = scenes_small[name]
     st = ctx.upload_build(sc)
     nodes, root = ctx.download_nodes()
-    lo, hi = prim_bounds(sc)
-    assert st.n_nodes == sc.n_prims - 1 == len(nodes) and root == 0
+    lo, hi, to_host_slot = device_bounds(ctx, sc)
+    assert st.n_nodes == sc.n_prims - 1 == len(nodes) and 0 <= root < len(nodes)
     assert check_tree(nodes, root, lo, hi) == st.depth <= 64
     assert st.sah_cost > 1.0 and abs(ctx.scene_quality() - st.sah_cost) < 0.02 * st.sah_cost  # padded vs unpadded boxes
     w, h = sc.image_size(96)
@@ -83,6 +98,9 @@ def test_device_built_tree_is_valid_and_renders_identically(ctx, scenes_small, n
     omean, orgb, cnt = O.render(sc, p)  # oracle: host SAH tree, canonical ties
     assert stats.rays_cast == cnt.rays and same(mean, omean) and np.array_equal(rgb, orgb)
     # the host-side validator of mi_scene_upload accepts the device-built tree
+    refs = nodes[:, 12:14].view(np.int32)           # leaf refs: device slots -> the host scene's slots
+    leaf = refs < 0
+    refs[leaf] = ~to_host_slot[~refs[leaf]].astype(np.int32)
     soa = N.SceneSoA.from_buffer_copy(sc.soa.contents)
     soa.n_nodes, soa.root_ref = len(nodes), root
     soa.nodes = nodes.ctypes.data_as(C.POINTER(C.c_float))
@@ -107,8 +125,8 @@ def test_device_build_edge_cases(ctx):
     sc = P.Scene.from_text(H + CAM + tri * 100)
     st = ctx.upload_build(sc)
     assert st.n_nodes == 99 and st.depth <= 8
-    lo, hi = prim_bounds(sc)
     nodes, root = ctx.download_nodes()
+    lo, hi, _ = device_bounds(ctx, sc)
     check_tree(nodes, root, lo, hi)
     ids, t, _ = ctx.trace_primary(32, 32, 1)
     oi, ot, _, _ = O.trace_primary(sc, 32, 32, 1, O.BRUTE)
@@ -127,14 +145,34 @@ def test_device_build_rejects_bad_input(ctx, scenes_small):
     ctx.upload(sc)
 
 
-def test_device_build_quality_and_time_on_the_bench_scene(ctx):
+def test_device_build_quality_and_time_on_the_bench_scene(ctx, monkeypatch):
     sc = scenes.blob_scene(6)
-    st = ctx.upload_build(sc)
+    st = ctx.upload_build(sc)                       # default builder: PLOC
+    ploc = ctx.scene_quality()
+    monkeypatch.setenv("MI_TRACER_BUILDER", "lbvh")
+    st_l = ctx.upload_build(sc)
     lbvh = ctx.scene_quality()
+    monkeypatch.delenv("MI_TRACER_BUILDER")
     ctx.upload(sc)
     sah = ctx.scene_quality()
-    print(f"\nblob82k: LBVH {st.ms_build:.2f} ms on the device, depth {st.depth}, SAH cost {lbvh:.1f} vs host binned-SAH {sah:.1f}")
-    assert st.depth <= 64 and sah <= lbvh < 3.0 * sah
+    print(f"\nblob82k: PLOC {st.ms_build:.2f} ms depth {st.depth} SAH cost {ploc:.1f} | LBVH {st_l.ms_build:.2f} ms depth {st_l.depth} "
+          f"SAH cost {lbvh:.1f} | host binned SAH {sah:.1f}")
+    assert st.depth <= 64 and st_l.depth <= 64 and 0.8 * sah <= ploc <= lbvh < 3.0 * sah
+
+
+@pytest.mark.parametrize("builder", ["lbvh", "ploc"])
+def test_both_device_builders_give_valid_trees(ctx, scenes_small, monkeypatch, builder):
+    monkeypatch.setenv("MI_TRACER_BUILDER", builder)
+    for name in ("glass", "blob3"):
+        sc = scenes_small[name]
+        st = ctx.upload_build(sc)
+        nodes, root = ctx.download_nodes()
+        lo, hi, _ = device_bounds(ctx, sc)
+        assert check_tree(nodes, root, lo, hi) == st.depth
+        p = P.Context.params(48, 48, 2, 3, seed=4)
+        mean, rgb, _ = ctx.render(p)
+        omean, orgb, _ = O.render(sc, p)
+        assert same(mean, omean) and np.array_equal(rgb, orgb)
 
 
 def test_device_and_host_trees_render_the_same_image_on_a_larger_mesh(ctx):
