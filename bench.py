@@ -195,7 +195,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": args.workload, "image": [w, h], "samples_per_dim": samples, "depth": depth,
                        "primitives": scene.n_prims,
-                       "bvh": "device LBVH" if build else "host binned SAH", "bvh_depth": build.depth if build else scene.bvh_depth,
+                       "bvh": ("device " + (os.environ.get("MI_TRACER_BUILDER") or "ploc").upper()) if build else "host binned SAH", "bvh_depth": build.depth if build else scene.bvh_depth,
                        "bvh_sah_cost": sah_cost, "bvh_build_ms": build.ms_build if build else None, "sharding": f"tile32x{world}",
                        "exchange": None if world == 1 else ("RCCL gather of RGBA8 tiles to rank 0" if args.backend == "nccl" else "REHEARSAL: gloo, all ranks on one GPU"),
                        "rays_per_step": rays_all / args.steps},
