@@ -5,11 +5,13 @@
 // names BVH quality as "the significant factor".  This builder is not a restatement of
 // that algorithm ("not to be replicated") — the closest hit does not depend on
 // the tree (canonical tie rule + padded boxes), so any valid tree renders
-// the same image bit for bit.  It is an LBVH (Karras 2012): 30-bit Morton codes of the
-// primitive centroids, one radix sort (hipCUB), every interior node found independently
-// from the longest common prefix of neighbouring keys, boxes fitted bottom-up, then
-// emitted in the 64-B node format of include/mi_tracer.h (both child boxes in the
-// parent).  Primitive records are not moved: leaf refs are ~slot of the caller's order.
+// the same image bit for bit.  30-bit Morton codes of the primitive centroids, one radix
+// sort (hipCUB), primitive records gathered into that order, then either PLOC (default:
+// rounds of nearest-neighbour search in a window, mutual pairs merge) or an LBVH (Karras
+// 2012: every interior node found independently from the longest common prefix of
+// neighbouring keys, boxes fitted bottom-up); both emit the 64-B node format of
+// include/mi_tracer.h (both child boxes in the parent), which is then collapsed into the
+// 4-wide nodes the traversal kernels walk.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
