@@ -379,3 +379,34 @@ k_build_permute(int n, uint32_t n_tri, uint32_t *sorted_slot, const uint32_t *tr
     dst.pb[now] = src.pb[old];
     sorted_slot[i] = now;
 }
+
+// ---- treelet: copies of the top of the 4-wide tree, appended behind it -------------------
+// One thread: breadth-first from the root, at most `max_nodes` nodes within `max_levels`
+// levels below the root; refs among the copied nodes are redirected to the copies.  The
+// traversal kernels keep nodes [base, base + count) in LDS (DevScene::treelet_*).  Mirrors
+// the host-side construction in install_bvh4() (mi_tracer.hip).  out[0] = count.
+__global__ void k_build_treelet(float *nodes4, int root4, int base, int max_nodes, int max_levels, int empty_ref, int *out) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    int top[128];
+    int n_top = 1, level_end = 1, lvl = 0;
+    top[0] = root4;
+    for (int q = 0; q < n_top && lvl < max_levels; q++) {
+        for (int k = 0; k < 4; k++) {
+            const int r = __float_as_int(nodes4[32 * (size_t)top[q] + 24 + k]);
+            if (r >= 0 && r != empty_ref && n_top < max_nodes) top[n_top++] = r;
+        }
+        if (q + 1 == level_end) { level_end = n_top; lvl++; }
+    }
+    for (int k = 0; k < n_top; k++) {
+        const float *src = nodes4 + 32 * (size_t)top[k];
+        float *dst = nodes4 + 32 * (size_t)(base + k);
+        for (int j = 0; j < 32; j++) dst[j] = src[j];
+        for (int j = 0; j < 4; j++) {
+            const int r = __float_as_int(src[24 + j]);
+            if (r < 0 || r == empty_ref) continue;
+            for (int t = 0; t < n_top; t++)
+                if (top[t] == r) { dst[24 + j] = __int_as_float(base + t); break; }
+        }
+    }
+    out[0] = n_top;
+}

@@ -42,7 +42,12 @@ struct DevScene {
     // Cubemap background or nullptr (white): 6 x (width, height, byte offset) as int32, then
     // at byte 128 the RGB8 texels of the six faces (+x,-x,+y,-y,+z,-z; row 0 = bottom row).
     const int32_t *cube;
+    // Treelet: nodes with index >= treelet_base are copies of the top of the tree (breadth
+    // first from the root, at most MI_TREELET nodes) that every workgroup keeps in LDS.
+    int32_t treelet_base, treelet_count;
 };
+#define MI_TREELET 69        // nodes: with the 16-KB stack, six workgroups of k_extend still fit the CU's 160 KB of LDS
+#define MI_TREELET_LEVELS 4  // root + up to four levels below it, breadth first
 
 struct f3 {
     float x, y, z;
@@ -426,8 +431,11 @@ __device__ __forceinline__ void cswap(bool sw, float &ka, float &kb, int &ra, in
     const int r0 = sw ? rb : ra, r1 = sw ? ra : rb;
     ka = k0; kb = k1; ra = r0; rb = r1;
 }
-__device__ __forceinline__ void node_phase(const DevScene &sc, Lane &L, lds_int *stack, int *my_ovf, size_t ovf_stride) {
-    const char *nd = (const char *)sc.nodes + ((uint32_t)L.cur << 7);
+__device__ __forceinline__ void node_phase(const DevScene &sc, Lane &L, lds_int *stack, int *my_ovf, size_t ovf_stride, const float4 *treelet) {
+    // one generic (flat) load per 16 B serves both: lanes at the top of the tree read the LDS
+    // copy, the others global memory
+    const char *nd = L.cur >= sc.treelet_base ? (const char *)treelet + ((uint32_t)(L.cur - sc.treelet_base) << 7)
+                                               : (const char *)sc.nodes + ((uint32_t)L.cur << 7);
     const float4 lx = *(const float4 *)(nd), ly = *(const float4 *)(nd + 16), lz = *(const float4 *)(nd + 32);
     const float4 hx = *(const float4 *)(nd + 48), hy = *(const float4 *)(nd + 64), hz = *(const float4 *)(nd + 80);
     const int4 refs = *(const int4 *)(nd + 96);
@@ -507,6 +515,10 @@ k_extend(DevScene sc, const uint32_t *count_ptr, uint32_t fixed_count, uint32_t 
          const uint32_t *tail_level, int level) {
     __shared__ int lds_stack[MI_LDS_STACK * MI_BLOCK];
     if (!PRIMARY && tail_level && tail_took_over(tail_level, level)) return;
+    __shared__ float4 lds_treelet[MI_TREELET * 8];
+    for (int i = threadIdx.x; i < sc.treelet_count * 8; i += MI_BLOCK) lds_treelet[i] = sc.nodes[(size_t)sc.treelet_base * 8 + i];
+    __syncthreads();
+
     const int lane = threadIdx.x & 63;
     lds_int *stack = (lds_int *)lds_stack + threadIdx.x;
     const size_t ovf_stride = (size_t)gridDim.x * MI_BLOCK;
@@ -594,7 +606,7 @@ k_extend(DevScene sc, const uint32_t *count_ptr, uint32_t fixed_count, uint32_t 
                 atomicAdd(&work_stats[8 + (depth < 40 ? depth : 39)], 1ull);
 #endif
             }
-            node_phase(sc, L, stack, my_ovf, ovf_stride);
+            node_phase(sc, L, stack, my_ovf, ovf_stride, lds_treelet);
         }
         if (active && L.cur == MI_DONE) {
             hits[slot] = make_float4(L.h.t, __int_as_float(L.h.slot), L.h.u, L.h.v);
@@ -874,6 +886,9 @@ k_tail(DevScene sc, ShardGeom g, uint32_t pix0, uint32_t npix, int level0, int d
     const uint32_t tl = *tail_level;
     // same decision in every wave: tl is only ever written with level0 by this launch
     if (n == 0 || n > threshold || (tl != 0 && tl != (uint32_t)level0)) return;
+    __shared__ float4 lds_treelet[MI_TREELET * 8];
+    for (int i = threadIdx.x; i < sc.treelet_count * 8; i += MI_BLOCK) lds_treelet[i] = sc.nodes[(size_t)sc.treelet_base * 8 + i];
+    __syncthreads();
     const int lane = threadIdx.x & 63;
     if (blockIdx.x == 0 && threadIdx.x == 0) *tail_level = (uint32_t)level0;
     lds_int *stack = (lds_int *)lds_stack + threadIdx.x;
@@ -947,7 +962,7 @@ k_tail(DevScene sc, ShardGeom g, uint32_t pix0, uint32_t npix, int level0, int d
         } else if (nl > 0 && (nl >= leaf_min || nn == 0)) {
             if (want_leaf) leaf_phase(sc, L, stack, my_ovf, ovf_stride);
         } else if (want_node) {
-            node_phase(sc, L, stack, my_ovf, ovf_stride);
+            node_phase(sc, L, stack, my_ovf, ovf_stride, lds_treelet);
         }
         act = __ballot(active);
     } while (more || act != 0ull);

@@ -313,7 +313,36 @@ static mi_status upload_prims(mi_ctx *c, const mi_scene_soa *s) {
 // Collapses the binary tree (host copy) into the 4-wide tree the kernels walk and uploads it.
 static mi_status install_bvh4(mi_ctx *c, const float *nodes2, int32_t root2) {
     std::vector<float> n4;
-    const int32_t root4 = collapse_bvh4(nodes2, root2, n4);
+    int32_t root4 = collapse_bvh4(nodes2, root2, n4);
+    // treelet: append copies of the root, its children and grandchildren (breadth first); refs
+    // among them point at the copies, the root ref at the root's copy
+    c->sc.treelet_base = (int32_t)(n4.size() / 32);
+    c->sc.treelet_count = 0;
+    if (root4 >= 0 && !getenv("MI_TRACER_NO_TREELET")) {
+        const int32_t base = c->sc.treelet_base;
+        std::vector<int32_t> top{root4};
+        for (size_t q = 0, level_end = 1, lvl = 0; q < top.size() && lvl < MI_TREELET_LEVELS; q++) {
+            for (int k = 0; k < 4; k++) {
+                int32_t r;
+                memcpy(&r, &n4[32 * (size_t)top[q] + 24 + k], 4);
+                if (r >= 0 && r != MI_DONE && top.size() < MI_TREELET) top.push_back(r);
+            }
+            if (q + 1 == level_end) { level_end = top.size(); lvl++; }
+        }
+        std::vector<int32_t> copy_of(n4.size() / 32, -1);
+        for (size_t k = 0; k < top.size(); k++) copy_of[top[k]] = base + (int32_t)k;
+        for (size_t k = 0; k < top.size(); k++) {
+            std::vector<float> node(n4.begin() + 32 * (size_t)top[k], n4.begin() + 32 * (size_t)top[k] + 32);
+            for (int j = 0; j < 4; j++) {
+                int32_t r;
+                memcpy(&r, &node[24 + j], 4);
+                if (r >= 0 && r != MI_DONE && copy_of[r] >= 0) { r = copy_of[r]; memcpy(&node[24 + j], &r, 4); }
+            }
+            n4.insert(n4.end(), node.begin(), node.end());
+        }
+        c->sc.treelet_count = (int32_t)top.size();
+        root4 = base;
+    }
     HIPCHK(c->nodes4.ensure(std::max<size_t>(n4.size() * 4, 16)));
     if (!n4.empty()) HIPCHK(hipMemcpy(c->nodes4.p, n4.data(), n4.size() * 4, hipMemcpyHostToDevice));
     c->sc.nodes = c->nodes4.as<float4>();
@@ -427,6 +456,8 @@ MI_API mi_status mi_scene_upload_build(mi_ctx *c, const mi_scene_soa *s, const f
     const char *builder = getenv("MI_TRACER_BUILDER");
     const bool use_ploc = !(builder && !strcmp(builder, "lbvh"));
     int32_t root2 = 0, root4 = 0;
+    uint32_t n4 = 0;
+    int treelet_n = 0;
     auto body = [&]() -> mi_status {
         HIPCHK(verts.ensure(std::max<size_t>((size_t)s->n_tri * 36, 16)));
         if (s->n_tri) HIPCHK(hipMemcpyAsync(verts.p, tri_verts, (size_t)s->n_tri * 36, hipMemcpyHostToDevice, st));
@@ -540,19 +571,29 @@ MI_API mi_status mi_scene_upload_build(mi_ctx *c, const mi_scene_soa *s, const f
         // 4-wide collapse on the device: even-depth flags (+ tree depth), prefix sum -> new indices, emit
         hipLaunchKernelGGL(k_build_even_depth, ngrid, block, 0, st, (int)(n - 1), par_n.as<int>(), flags.as<uint32_t>(), height.as<int>());
         HIPCHK(hipcub::DeviceScan::ExclusiveSum(cub_tmp.p, scan_bytes, flags.as<uint32_t>(), vals_a.as<uint32_t>(), (int)(n - 1), st));
-        HIPCHK(c->nodes4.ensure((size_t)(n - 1) * 128)); // upper bound: every binary node survives
+        HIPCHK(c->nodes4.ensure((size_t)(n - 1 + MI_TREELET) * 128)); // upper bound: every binary node survives; + the treelet copies
         hipLaunchKernelGGL(k_build_emit4, ngrid, block, 0, st, (int)(n - 1), c->nodes.as<float4>(), flags.as<uint32_t>(), vals_a.as<uint32_t>(),
                            c->nodes4.as<float>(), (int)MI_DONE);
+        HIPCHK(hipGetLastError());
+        // treelet: where the 4-wide nodes end and which of them is the root, then the copies behind them
+        uint32_t root4u = 0, last_idx = 0, last_flag = 0;
+        HIPCHK(hipMemcpyAsync(&root4u, vals_a.as<uint32_t>() + root2, 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(&last_idx, vals_a.as<uint32_t>() + (n - 2), 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(&last_flag, flags.as<uint32_t>() + (n - 2), 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        n4 = last_idx + last_flag;
+        if (n4 == 0 || n4 > n - 1 || root4u >= n4) return fail(MI_ERR_HIP, "4-wide collapse produced %u nodes, root %u", n4, root4u);
+        hipLaunchKernelGGL(k_build_treelet, dim3(1), dim3(64), 0, st, c->nodes4.as<float>(), (int)root4u, (int)n4, MI_TREELET, MI_TREELET_LEVELS,
+                           (int)MI_DONE, height.as<int>() + 1);
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(e1, st));
         int h_root = 0;
         double area_sum = 0;
-        uint32_t root4u = 0;
         HIPCHK(hipMemcpyAsync(&h_root, height.p, 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(&treelet_n, height.as<int>() + 1, 4, hipMemcpyDeviceToHost, st));
         HIPCHK(hipMemcpyAsync(&area_sum, area.p, 8, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipMemcpyAsync(&root4u, vals_a.as<uint32_t>() + root2, 4, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
-        root4 = (int32_t)root4u;
+        root4 = (int32_t)n4; // the root's copy is the first node of the treelet
         float ms = 0;
         HIPCHK(hipEventElapsedTime(&ms, e0, e1));
         if (h_root > MI_MAX_DEPTH) return fail(MI_ERR_INVALID, "device-built BVH is %d levels deep (limit %d)", h_root, MI_MAX_DEPTH);
@@ -573,6 +614,8 @@ MI_API mi_status mi_scene_upload_build(mi_ctx *c, const mi_scene_soa *s, const f
     c->n_nodes = n - 1;
     c->sc.nodes = c->nodes4.as<float4>(); // collapsed on the device above
     c->sc.root_ref = root4;
+    c->sc.treelet_base = (int32_t)n4;
+    c->sc.treelet_count = treelet_n;
     c->has_scene = true;
     return MI_OK;
 }
