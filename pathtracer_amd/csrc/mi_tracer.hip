@@ -123,6 +123,10 @@ MI_API mi_status mi_ctx_create(int device_id, mi_ctx **out) {
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_tail, MI_BLOCK, 0) == hipSuccess && occ > 0)
         c->tail_wg_per_cu = std::min(occ, c->extend_wg_per_cu);
     c->tail_wg_per_cu = env_int("MI_TRACER_TAIL_WG_PER_CU", 1, 16, c->tail_wg_per_cu);
+    // the same for k_extend: never more persistent workgroups than are resident at once (LDS: 16-KB stack + treelet)
+    int occ_e = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_e, k_extend<false, false, false>, MI_BLOCK, 0) == hipSuccess && occ_e > 0)
+        c->extend_wg_per_cu = std::min(c->extend_wg_per_cu, occ_e);
     hipError_t es = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (es != hipSuccess) { delete c; return fail(MI_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(es)); }
     es = hipHostMalloc((void **)&c->h_totals, kTotals * sizeof(uint64_t), hipHostMallocDefault);
