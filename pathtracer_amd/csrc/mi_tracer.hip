@@ -74,6 +74,7 @@ struct mi_ctx {
     int refill_min = 20;        // MI_TRACER_REFILL: idle lanes that trigger a refill
     int leaf_min = 16;          // MI_TRACER_LEAF_MIN: lanes with a pending leaf that trigger a leaf phase
     int shade_min = 24;         // MI_TRACER_SHADE_MIN: lanes waiting to be shaded that trigger a shade phase of k_tail
+    int shade_wg_per_cu = 8;    // MI_TRACER_SHADE_WG_PER_CU: workgroups of k_shade per CU (grid-stride loop)
     int tail_wg_per_cu = 4;     // workgroups of k_tail resident per CU (occupancy query at context creation)
     int tail_threshold = 1500000; // MI_TRACER_TAIL: k_tail takes over a batch once a level has at most this many rays (0 = off)
 };
@@ -123,6 +124,12 @@ MI_API mi_status mi_ctx_create(int device_id, mi_ctx **out) {
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_tail, MI_BLOCK, 0) == hipSuccess && occ > 0)
         c->tail_wg_per_cu = std::min(occ, c->extend_wg_per_cu);
     c->tail_wg_per_cu = env_int("MI_TRACER_TAIL_WG_PER_CU", 1, 16, c->tail_wg_per_cu);
+    // k_shade walks its stream with a grid-stride loop: a grid that is a multiple of what is resident
+    // at once keeps the last round full (8 per CU against 5 resident measured 9 % slower than 5 or 10)
+    int occ_s = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_s, k_shade<false>, MI_BLOCK, 0) == hipSuccess && occ_s > 0)
+        c->shade_wg_per_cu = 2 * occ_s;
+    c->shade_wg_per_cu = env_int("MI_TRACER_SHADE_WG_PER_CU", 1, 32, c->shade_wg_per_cu);
     // the same for k_extend: never more persistent workgroups than are resident at once (LDS: 16-KB stack + treelet)
     int occ_e = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_e, k_extend<false, false, false>, MI_BLOCK, 0) == hipSuccess && occ_e > 0)
@@ -697,7 +704,7 @@ MI_API mi_status mi_render_device(mi_ctx *c, const mi_render_params *p, void *d_
     // Ray streams: MI_SUB sub-streams of `segcap` positions each.  Shade workgroup b appends to
     // sub-stream b % MI_SUB and handles at most
     // ceil((n_virtual + 255) / sgrid) + 256 rays (grid-stride loop over 256-ray groups), n_virtual <= cap + 64*MI_SUB.
-    const int sgrid = (int)std::min<int64_t>((int64_t)c->n_cu * 8, (int64_t)(cap + MI_BLOCK - 1) / MI_BLOCK);
+    const int sgrid = (int)std::min<int64_t>((int64_t)c->n_cu * c->shade_wg_per_cu, (int64_t)(cap + MI_BLOCK - 1) / MI_BLOCK);
     const size_t wg_per_sub = ((size_t)sgrid + MI_SUB - 1) / MI_SUB;
     const size_t segcap64 = (wg_per_sub * ((cap + 64 * MI_SUB + MI_BLOCK + (size_t)sgrid - 1) / (size_t)sgrid + MI_BLOCK) + 63) / 64 * 64;
     if (segcap64 * MI_SUB >= ((size_t)1 << 32)) return fail(MI_ERR_INVALID, "batch too large for 32-bit stream positions");

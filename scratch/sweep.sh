@@ -1,5 +1,5 @@
 set -e
-for r in 8 32 64; do
-  sed "s/#define MI_PLOC_RADIUS 16/#define MI_PLOC_RADIUS $r/" pathtracer_amd/csrc/mi_bvh_build.h > /tmp/mi_bvh_build.h
-  echo "== radius $r"
+for v in 4 5 8 10 15 20; do
+  echo "== MI_TRACER_SHADE_WG_PER_CU=$v"
+  MI_TRACER_SHADE_WG_PER_CU=$v timeout -k 10 60 python scratch/dbg.py 2>&1 | tail -1
 done
