@@ -822,18 +822,38 @@ k_shade(DevScene sc, ShardGeom g, uint32_t pix0, uint32_t npix, int level, int d
     const uint32_t out_base = (blockIdx.x % MI_SUB) * out.segcap;
     // every thread of a workgroup runs the same number of iterations (queue_reserve has barriers)
     const uint32_t n_round = (n_virtual + (MI_BLOCK - 1u)) & ~(MI_BLOCK - 1u);
-    for (uint32_t i = blockIdx.x * MI_BLOCK + threadIdx.x; i < n_round; i += stride) {
-        bool alive = false;
-        uint32_t slot = 0, pos_in = 0;
-        bool live = false;
+    // The stream records of the NEXT iteration are fetched before this iteration's are used
+    // (software pipelining): the kernel is bound by memory latency x resident waves, and this
+    // doubles what each wave has in flight on its longest (HBM) leg.
+    struct In { bool live; uint32_t pos; float4 o4, d4, T, h4; };
+    auto fetch = [&](uint32_t i) {
+        In r;
+        r.live = false; r.pos = 0;
+        r.o4 = r.d4 = r.h4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        r.T = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
         if (i < n_virtual) {
             uint32_t first, end;
             stream_chunk(PRIMARY ? nullptr : count_ptr, n_fixed, in.segcap, __builtin_amdgcn_readfirstlane(i >> 6), first, end);
-            pos_in = first + (i & 63u);
-            live = pos_in < end;
+            r.pos = first + (i & 63u);
+            r.live = r.pos < end;
         }
+        if (r.live) {
+            if (!PRIMARY) { r.o4 = in.o[r.pos]; r.d4 = in.d[r.pos]; r.T = in.thr[r.pos]; }
+            r.h4 = hits[r.pos];
+        }
+        return r;
+    };
+    const uint32_t i_first = blockIdx.x * MI_BLOCK + threadIdx.x;
+    In nxt = fetch(i_first);
+    for (uint32_t i = i_first; i < n_round; i += stride) {
+        const In cur = nxt;
+        nxt = fetch(i + stride); // beyond n_round: nothing is loaded
+        bool alive = false;
+        uint32_t slot = 0;
+        const uint32_t pos_in = cur.pos;
+        bool live = cur.live;
         f3 o = mk3(0, 0, 0), d = mk3(0, 0, 0);
-        float4 T = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+        float4 T = cur.T;
         int px = 0, py = 0;
         uint32_t samp = 0;
         if (live) {
@@ -842,11 +862,9 @@ k_shade(DevScene sc, ShardGeom g, uint32_t pix0, uint32_t npix, int level, int d
                 live = primary_ray(sc, g, pix0, npix, slot, o, d, px, py, samp);
                 if (!live) path_out[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             } else {
-                float4 o4 = in.o[pos_in];
-                slot = (uint32_t)__float_as_int(o4.w);
-                o = xyz(o4);
-                d = xyz(in.d[pos_in]);
-                T = in.thr[pos_in];
+                slot = (uint32_t)__float_as_int(cur.o4.w);
+                o = xyz(cur.o4);
+                d = xyz(cur.d4);
                 samp = slot / npix;
                 uint32_t lp = slot - samp * npix;
                 local_to_pixel(g, slot_to_local(g, pix0 + lp), px, py);
@@ -855,7 +873,7 @@ k_shade(DevScene sc, ShardGeom g, uint32_t pix0, uint32_t npix, int level, int d
         f3 no = mk3(0, 0, 0), nd = mk3(0, 0, 0);
         float4 Tn = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         if (live) {
-            float4 h4 = hits[pos_in];
+            const float4 h4 = cur.h4;
             alive = shade_path(sc, seed, path_id(g, px, py, samp), level, depth_left, slot, o, d, T, h4.x, __float_as_int(h4.y), h4.z, h4.w,
                                hist, cap, path_out, no, nd, Tn);
         }
