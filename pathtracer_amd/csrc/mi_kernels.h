@@ -591,7 +591,19 @@ k_extend(DevScene sc, const uint32_t *count_ptr, uint32_t fixed_count, uint32_t 
         const bool want_leaf = active && L.cur < 0;
         const bool want_node = active && L.cur >= 0 && L.cur != MI_DONE;
         const int nl = __popcll(__ballot(want_leaf)), nn = __popcll(__ballot(want_node));
-        if (nl > 0 && (nl >= leaf_min || nn == 0)) {
+        if (!more) {
+            // Draining (no rays left to refill with): the wave's remaining time is a latency
+            // chain, so every lane advances every iteration, leaves and nodes both.
+            if (want_leaf) {
+                if (COUNT) n_leaves++;
+                leaf_phase(sc, L, stack, my_ovf, ovf_stride);
+                if (ANY && L.h.slot >= 0) { L.cur = MI_DONE; L.sp = 0; }
+            }
+            if (want_node) {
+                if (COUNT) { n_nodes++; ray_steps++; }
+                node_phase(sc, L, stack, my_ovf, ovf_stride, lds_treelet);
+            }
+        } else if (nl > 0 && (nl >= leaf_min || nn == 0)) {
             if (want_leaf) {
                 if (COUNT) n_leaves++;
                 leaf_phase(sc, L, stack, my_ovf, ovf_stride);
@@ -977,10 +989,11 @@ k_tail(DevScene sc, ShardGeom g, uint32_t pix0, uint32_t npix, int level0, int d
                 }
             }
             n_extra += (uint32_t)__popcll(__ballot(cont));
-        } else if (nl > 0 && (nl >= leaf_min || nn == 0)) {
+        } else {
+            // The tail is a latency chain (few rays, whole paths per lane): leaves and nodes
+            // both advance in every iteration (1.19 -> 1.04 ms on C3).
             if (want_leaf) leaf_phase(sc, L, stack, my_ovf, ovf_stride);
-        } else if (want_node) {
-            node_phase(sc, L, stack, my_ovf, ovf_stride, lds_treelet);
+            if (want_node) node_phase(sc, L, stack, my_ovf, ovf_stride, lds_treelet);
         }
         act = __ballot(active);
     } while (more || act != 0ull);
