@@ -20,7 +20,7 @@
 #include <stdint.h>
 
 #define MI_BLOCK 256          // threads per workgroup = 4 waves of 64
-#define MI_LDS_STACK 16       // traversal stack entries per lane held in LDS
+#define MI_LDS_STACK 12       // traversal stack entries per lane held in LDS
 #define MI_MAX_DEPTH 64       // deepest (binary) tree the uploader accepts
 #define MI_MAX_STACK 192      // up to three pushes per level of the 4-wide tree collapsed from it
 #define MI_NO_HIT 12345678.9f // ray.h:14
@@ -46,7 +46,7 @@ struct DevScene {
     // first from the root, at most MI_TREELET nodes) that every workgroup keeps in LDS.
     int32_t treelet_base, treelet_count;
 };
-#define MI_TREELET 69        // nodes: with the 16-KB stack, six workgroups of k_extend still fit the CU's 160 KB of LDS
+#define MI_TREELET 69        // nodes: with the 12-KB stack, seven workgroups of k_extend still fit the CU's 160 KB of LDS (84 nodes measured no better)
 #define MI_TREELET_LEVELS 4  // root + up to four levels below it, breadth first
 
 struct f3 {

@@ -70,7 +70,8 @@ struct mi_ctx {
     std::vector<hipEvent_t> ev;
     uint64_t *h_totals = nullptr; // pinned
     // tuning knobs (defaults measured on MI355X, overridable through the environment)
-    int extend_wg_per_cu = 6;   // MI_TRACER_EXTEND_WG_PER_CU: persistent workgroups of k_extend per CU
+    int extend_wg_per_cu = 7;   // MI_TRACER_EXTEND_WG_PER_CU: persistent workgroups of k_extend per CU (clamped by the occupancy query)
+    int extend_wg_primary = 6;  // the same for the level-0 variant, which holds more registers
     int refill_min = 20;        // MI_TRACER_REFILL: idle lanes that trigger a refill
     int leaf_min = 16;          // MI_TRACER_LEAF_MIN: lanes with a pending leaf that trigger a leaf phase
     int shade_min = 24;         // MI_TRACER_SHADE_MIN: lanes waiting to be shaded that trigger a shade phase of k_tail
@@ -130,10 +131,14 @@ MI_API mi_status mi_ctx_create(int device_id, mi_ctx **out) {
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_s, k_shade<false>, MI_BLOCK, 0) == hipSuccess && occ_s > 0)
         c->shade_wg_per_cu = 2 * occ_s;
     c->shade_wg_per_cu = env_int("MI_TRACER_SHADE_WG_PER_CU", 1, 32, c->shade_wg_per_cu);
-    // the same for k_extend: never more persistent workgroups than are resident at once (LDS: 16-KB stack + treelet)
+    // the same for k_extend: never more persistent workgroups than are resident at once (LDS: 12-KB stack +
+    // treelet allow 7; the level-0 variant's registers allow 6)
     int occ_e = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_e, k_extend<false, false, false>, MI_BLOCK, 0) == hipSuccess && occ_e > 0)
         c->extend_wg_per_cu = std::min(c->extend_wg_per_cu, occ_e);
+    c->extend_wg_primary = c->extend_wg_per_cu;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_e, k_extend<false, true, false>, MI_BLOCK, 0) == hipSuccess && occ_e > 0)
+        c->extend_wg_primary = std::min(c->extend_wg_primary, occ_e);
     hipError_t es = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (es != hipSuccess) { delete c; return fail(MI_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(es)); }
     es = hipHostMalloc((void **)&c->h_totals, kTotals * sizeof(uint64_t), hipHostMallocDefault);
@@ -750,7 +755,7 @@ MI_API mi_status mi_render_device(mi_ctx *c, const mi_render_params *p, void *d_
                                    c->totals.as<unsigned long long>() + 7, c->leaf_min, c->shade_min);
             if (per_launch) HIPCHK(hipEventRecord(c->ev[evi++], st));
 #define MI_EXTEND_ARGS(PRIM)                                                                                                   \
-    dim3(egrid), dim3(MI_BLOCK), 0, st, c->sc, (PRIM) ? (const uint32_t *)nullptr : cnt + k * kLevelWords,                   \
+    dim3((PRIM) ? c->n_cu * c->extend_wg_primary : egrid), dim3(MI_BLOCK), 0, st, c->sc, (PRIM) ? (const uint32_t *)nullptr : cnt + k * kLevelWords,                   \
         (PRIM) ? (uint32_t)nslots : 0u, segcap, sin.o, sin.d, c->hits.as<float4>(), c->ovf.as<int>(), ws,                          \
         c->refill_min, c->leaf_min, g, pix0, np, cnt, tail_level, k
             if (k == 0) {
