@@ -2,6 +2,8 @@
 (the generators of pathtracer_amd/scenes.py plus random sphere fields with all four material
 branches), host-built or device-built trees, odd image sizes, tile sizes that are not
 multiples of 8, shards, multi-batch renders, depths -1..8."""
+import os
+
 import numpy as np
 import pytest
 
@@ -12,7 +14,12 @@ from oracle import oracle_py as O
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("seed", [11, 12, 13])
+# MI_FUZZ_SEEDS="100,101,..." runs other seeds (soak runs; combine with MI_TRACER_TAIL=0 to keep
+# every level in the per-level kernels, or a small value to move the hand-over to k_tail around)
+SEEDS = [int(x) for x in os.environ.get("MI_FUZZ_SEEDS", "11,12,13").split(",")]
+
+
+@pytest.mark.parametrize("seed", SEEDS)
 def test_random_configurations_match_the_oracle(ctx, seed):
     rng = np.random.default_rng(seed)
     H = scenes.HEADER
