@@ -206,6 +206,7 @@ def main():
                          "valu_tflops": valu_tflops, "valu_frac": valu_tflops / VALU_PEAK_TFLOPS,
                          "extend_share_of_step": (ms_extend / args.steps) / (dt / args.steps * 1e3),
                          "rays_in_kernel_per_step": rays_rank0_per_step,
+                         "pmc": pmc_record(args.workload, world),
                          "note": "achieved = algorithmic bytes (128 B per 4-wide node visit, 64 B per primitive test, 128 B ray-stream traffic "
                                  "per ray, counted on the GPU's own traversal) / k_extend time; the ~10 MB scene is L2/MALL "
                                  "resident, so most of these bytes never reach HBM (see traffic) and frac can exceed 1: the "
@@ -217,6 +218,17 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pmc_record(workload, world):
+    """L2 / L1 hit rates, VALU busy fraction and active lanes per VALU instruction of k_extend by level, from the
+    PMC passes committed under profiles/ (None if this workload was not profiled)."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    if world != 1 or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        rec = json.load(f).get(workload)
+    return {k: v for k, v in rec.items() if k.endswith("levels_0_1_2") or k == "counters_note"} if rec else None
 
 
 def pmc_traffic(workload, world):
