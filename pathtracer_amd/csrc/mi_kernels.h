@@ -508,7 +508,7 @@ __device__ __forceinline__ void leaf_phase(const DevScene &sc, Lane &L, lds_int 
 // ANY = true is the any-hit (occlusion) query: ray_d[i].w is the ray's maximum distance,
 // the lane stops at the first accepted primitive, and hits[i].y >= 0 means "occluded".
 template <bool COUNT, bool PRIMARY, bool ANY = false>
-__global__ void __launch_bounds__(MI_BLOCK)
+__global__ void __launch_bounds__(MI_BLOCK, 6)
 k_extend(DevScene sc, const uint32_t *count_ptr, uint32_t fixed_count, uint32_t segcap,
          const float4 *ray_o, const float4 *ray_d, float4 *hits, int *ovf, unsigned long long *work_stats, int refill_min,
          int leaf_min, ShardGeom g, uint32_t pix0, uint32_t npix, uint32_t *primary_count,
@@ -545,6 +545,14 @@ k_extend(DevScene sc, const uint32_t *count_ptr, uint32_t fixed_count, uint32_t 
     L.h = Hit{MI_NO_HIT, 0.0f, 0.0f, -1};
     L.o = L.d = L.inv = L.noi = mk3(0, 0, 0);
     unsigned long long act = 0ull; // ballot of `active`
+    // Level 0: the camera rays of a chunk are computed by all 64 lanes at once when the wave
+    // takes the chunk, and parked in LDS until the refills hand them out.  (Computed inside
+    // the refill, the ~200 instructions of the pixel and camera arithmetic ran about three
+    // times per chunk, each time for the third of the lanes that was idle: 38 % of the
+    // kernel's VALU instructions.)
+    __shared__ float lds_dir[PRIMARY ? 3 * MI_BLOCK : 1];
+    unsigned long long chunk_valid = 0ull; // wave-uniform: slots of the chunk that are real pixels
+    uint32_t chunk_first = 0;              // wave-uniform
     do {
         // Refill: whenever at least refill_min lanes are idle, hand them the next rays of
         // this wave's current chunk range, so rays of different traversal length do not
@@ -556,6 +564,20 @@ k_extend(DevScene sc, const uint32_t *count_ptr, uint32_t fixed_count, uint32_t 
                 rng_next = __builtin_amdgcn_readfirstlane(rng_next);
                 rng_end = __builtin_amdgcn_readfirstlane(rng_end);
                 chunk += n_waves;
+                if (PRIMARY) {
+                    chunk_first = rng_next;
+                    f3 co = mk3(0, 0, 0), cd = mk3(0, 0, 0);
+                    int px, py;
+                    uint32_t samp;
+                    const bool real = rng_next + (uint32_t)lane < rng_end &&
+                                      primary_ray(sc, g, pix0, npix, rng_next + (uint32_t)lane, co, cd, px, py, samp);
+                    chunk_valid = __ballot(real);
+                    n_primary += (uint32_t)__popcll(chunk_valid);
+                    lds_dir[threadIdx.x] = cd.x;
+                    lds_dir[MI_BLOCK + threadIdx.x] = cd.y;
+                    lds_dir[2 * MI_BLOCK + threadIdx.x] = cd.z;
+                    __builtin_amdgcn_wave_barrier(); // same wave reads below; LDS operations of a wave complete in order
+                }
             }
             if (rng_next < rng_end) {
                 const uint32_t rank = (uint32_t)__popcll(~act & ((1ull << lane) - 1ull));
@@ -565,13 +587,14 @@ k_extend(DevScene sc, const uint32_t *count_ptr, uint32_t fixed_count, uint32_t 
                 f3 o = mk3(0, 0, 0), d = mk3(0, 0, 0);
                 float t0 = MI_NO_HIT;
                 if (PRIMARY) {
+                    const uint32_t src = (idx - chunk_first) & 63u;
+                    take = take && ((chunk_valid >> src) & 1ull);
                     if (take) {
                         slot = idx;
-                        int px, py;
-                        uint32_t samp;
-                        take = primary_ray(sc, g, pix0, npix, slot, o, d, px, py, samp);
+                        const uint32_t at = (threadIdx.x & ~63u) + src;
+                        o = xyz(sc.eye); // camera.cu:9
+                        d = mk3(lds_dir[at], lds_dir[MI_BLOCK + at], lds_dir[2 * MI_BLOCK + at]);
                     }
-                    n_primary += (uint32_t)__popcll(__ballot(take));
                 } else if (take) {
                     slot = idx;
                     o = xyz(ray_o[idx]);

@@ -73,6 +73,7 @@ struct mi_ctx {
     int extend_wg_per_cu = 7;   // MI_TRACER_EXTEND_WG_PER_CU: persistent workgroups of k_extend per CU (clamped by the occupancy query)
     int extend_wg_primary = 6;  // the same for the level-0 variant, which holds more registers
     int refill_min = 20;        // MI_TRACER_REFILL: idle lanes that trigger a refill
+    int refill_primary = 12;    // MI_TRACER_REFILL_PRIMARY: the same at level 0, where a refill only reads parked camera rays
     int leaf_min = 16;          // MI_TRACER_LEAF_MIN: lanes with a pending leaf that trigger a leaf phase
     int shade_min = 24;         // MI_TRACER_SHADE_MIN: lanes waiting to be shaded that trigger a shade phase of k_tail
     int shade_wg_per_cu = 8;    // MI_TRACER_SHADE_WG_PER_CU: workgroups of k_shade per CU (grid-stride loop)
@@ -116,6 +117,7 @@ MI_API mi_status mi_ctx_create(int device_id, mi_ctx **out) {
     };
     c->extend_wg_per_cu = env_int("MI_TRACER_EXTEND_WG_PER_CU", 1, 16, c->extend_wg_per_cu);
     c->refill_min = env_int("MI_TRACER_REFILL", 1, 64, c->refill_min);
+    c->refill_primary = env_int("MI_TRACER_REFILL_PRIMARY", 1, 64, c->refill_primary);
     c->leaf_min = env_int("MI_TRACER_LEAF_MIN", 1, 64, c->leaf_min);
     c->shade_min = env_int("MI_TRACER_SHADE_MIN", 1, 64, c->shade_min);
     c->tail_threshold = env_int("MI_TRACER_TAIL", 0, 1 << 30, c->tail_threshold);
@@ -757,7 +759,7 @@ MI_API mi_status mi_render_device(mi_ctx *c, const mi_render_params *p, void *d_
 #define MI_EXTEND_ARGS(PRIM)                                                                                                   \
     dim3((PRIM) ? c->n_cu * c->extend_wg_primary : egrid), dim3(MI_BLOCK), 0, st, c->sc, (PRIM) ? (const uint32_t *)nullptr : cnt + k * kLevelWords,                   \
         (PRIM) ? (uint32_t)nslots : 0u, segcap, sin.o, sin.d, c->hits.as<float4>(), c->ovf.as<int>(), ws,                          \
-        c->refill_min, c->leaf_min, g, pix0, np, cnt, tail_level, k
+        (PRIM) ? c->refill_primary : c->refill_min, c->leaf_min, g, pix0, np, cnt, tail_level, k
             if (k == 0) {
                 if (count_work) hipLaunchKernelGGL((k_extend<true, true>), MI_EXTEND_ARGS(true));
                 else hipLaunchKernelGGL((k_extend<false, true>), MI_EXTEND_ARGS(true));
