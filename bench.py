@@ -171,8 +171,8 @@ def main():
         r = max(1, stc.rays_cast)
         nodes_per_ray, leaves_per_ray = stc.node_visits / r, stc.prim_tests / r
         # SURVEY 8d prices a visit of a binary node (2 boxes, 64 B, 54 flops); the kernels walk 4-wide nodes
-        # (4 boxes, 128 B, 108 flops) collapsed from the binary tree, so a node visit counts twice that
-        bytes_per_ray = 128.0 * nodes_per_ray + 64.0 * leaves_per_ray + 128.0
+        # collapsed from the binary tree: 4 boxes = 108 flops, and 64 B, because the boxes are 16-bit codes
+        bytes_per_ray = 64.0 * nodes_per_ray + 64.0 * leaves_per_ray + 128.0
         flops_per_ray = 108.0 * nodes_per_ray + 37.0 * leaves_per_ray + 160.0
         rays_rank0_per_step = rays_ext / args.steps   # rays traced by k_extend launches (k_tail's excluded)
         launches_per_step = max(1, n_ext // args.steps)
@@ -207,7 +207,7 @@ def main():
                          "extend_share_of_step": (ms_extend / args.steps) / (dt / args.steps * 1e3),
                          "rays_in_kernel_per_step": rays_rank0_per_step,
                          "pmc": pmc_record(args.workload, world),
-                         "note": "achieved = algorithmic bytes (128 B per 4-wide node visit, 64 B per primitive test, 128 B ray-stream traffic "
+                         "note": "achieved = algorithmic bytes (64 B per quantised 4-wide node visit, 64 B per primitive test, 128 B ray-stream traffic "
                                  "per ray, counted on the GPU's own traversal) / k_extend time; the ~10 MB scene is L2/MALL "
                                  "resident, so most of these bytes never reach HBM (see traffic) and frac can exceed 1: the "
                                  "kernel is VALU-issue/latency bound, not HBM bound (DESIGN.md section 3)"},

@@ -57,7 +57,9 @@ typedef enum mi_status {
  * Primitive slots: [0, n_tri) are triangles, [n_tri, n_tri+n_sph) are spheres
  * (slot - n_tri indexes the sphere arrays).
  * The library collapses this binary tree into the 4-wide tree its kernels walk (a node's
- * seats are its grandchildren) when the scene is uploaded; the caller never sees that form.
+ * seats are its grandchildren; 64-B nodes, child boxes as 16-bit plane codes rounded outward)
+ * when the scene is uploaded; the caller never sees that form.  Coordinates must be finite
+ * and smaller than 1e15 in magnitude.
  * root_ref: ref of the root (an interior node index, a leaf ref for a
  * one-primitive scene — bvh.cu:182-183 — or ignored when n_tri+n_sph == 0).
  */

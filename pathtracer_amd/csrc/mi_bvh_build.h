@@ -410,3 +410,47 @@ __global__ void k_build_treelet(float *nodes4, int root4, int base, int max_node
     }
     out[0] = n_top;
 }
+
+// ------------------------------------------------------------ quantised 4-wide nodes
+// fp32 4-wide nodes (128 B: lo.x[4] lo.y[4] lo.z[4] hi.x[4] hi.y[4] hi.z[4] refs[4] pad) -> the 64-B
+// nodes the traversal kernels read (DevScene::qnodes).  One thread per node.  A plane b on axis a
+// becomes n = (b - qb[a]) / qs[a], which the caller's choice of qs, qb keeps inside [0.51, 1.99]
+// for every plane inside the scene box; the code is bits 23..8 of the float n rounded DOWN for a
+// lower plane and UP for an upper plane, then moved MI_Q_PAD codes further out.  Planes outside
+// the scene box are clamped to it (what lies outside the root's box cannot be reached anyway).
+// Empty seats get an inverted box.
+__device__ __forceinline__ uint32_t q_encode(float b, float qs, float qb, bool upper) {
+    double n = ((double)b - (double)qb) / (double)qs;
+    n = n < 0.5 ? 0.5 : (n > 1.999 ? 1.999 : n);
+    const float f = upper ? __double2float_ru(n) : __double2float_rd(n);
+    const uint32_t m = __float_as_uint(f) - 0x3F000000u; // 24 bits: [0.5, 2) is two binades
+    uint32_t q = upper ? (m + 0xFFu) >> 8 : m >> 8;
+    if (upper) q = q + MI_Q_PAD > 0xFFFFu ? 0xFFFFu : q + MI_Q_PAD;
+    else q = q > MI_Q_PAD ? q - MI_Q_PAD : 0u;
+    return q;
+}
+__global__ void __launch_bounds__(256)
+k_quantize_nodes4(const float *nodes4, int n_nodes, float qs0, float qs1, float qs2, float qb0, float qb1, float qb2, int empty_ref, uint4 *out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_nodes) return;
+    const float *nd = nodes4 + 32 * (size_t)i;
+    const float qs[3] = {qs0, qs1, qs2}, qb[3] = {qb0, qb1, qb2};
+    uint32_t P[3][4];
+    int refs[4];
+    for (int c = 0; c < 4; c++) {
+        refs[c] = __float_as_int(nd[24 + c]);
+        for (int a = 0; a < 3; a++) {
+            if (refs[c] == empty_ref) {
+                P[a][c] = 0x0000FFFFu; // lower plane at the top code, upper plane at code 0
+            } else {
+                const uint32_t lo = q_encode(nd[4 * a + c], qs[a], qb[a], false), hi = q_encode(nd[12 + 4 * a + c], qs[a], qb[a], true);
+                P[a][c] = lo | hi << 16;
+            }
+        }
+    }
+    out[4 * (size_t)i + 0] = make_uint4(P[0][0], P[0][1], P[0][2], P[0][3]);
+    out[4 * (size_t)i + 1] = make_uint4(P[1][0], P[1][1], P[1][2], P[1][3]);
+    out[4 * (size_t)i + 2] = make_uint4(P[2][0], P[2][1], P[2][2], P[2][3]);
+    out[4 * (size_t)i + 3] = make_uint4((uint32_t)refs[0], (uint32_t)refs[1], (uint32_t)refs[2], (uint32_t)refs[3]);
+}
+

@@ -27,7 +27,13 @@
 #define MI_EPS 0.00001f       // ray.h:12
 
 struct DevScene {
-    const float4 *nodes; // 4 x float4 per interior node (layout: include/mi_tracer.h)
+    // The tree the kernels walk: 64-B quantised 4-wide nodes = px[4] py[4] pz[4] refs[4].  p?[c] packs
+    // the two planes of seat c on that axis as 16-bit codes (low half: lower plane, high half: upper
+    // plane).  A code q stands for the float F with bits 0x3F000000 | q << 8, a number in [0.5, 2)
+    // (two binades, 15 mantissa bits), and for the plane qs[a] * F + qb[a].  Codes are rounded outward
+    // by MI_Q_PAD steps, so a quantised box encloses the fp32 box it was made from.
+    const uint4 *qnodes;
+    float qs[3], qb[3];
     const float4 *tri;   // 4 x float4 per triangle slot: v0, uInv, vInv, nInv
     const float4 *tri_normal;
     const uint32_t *tri_mat; // 3 per triangle
@@ -46,7 +52,11 @@ struct DevScene {
     // first from the root, at most MI_TREELET nodes) that every workgroup keeps in LDS.
     int32_t treelet_base, treelet_count;
 };
-#define MI_TREELET 69        // nodes: with the 12-KB stack, seven workgroups of k_extend still fit the CU's 160 KB of LDS (84 nodes measured no better)
+#define MI_TREELET 69        // nodes (4.4 KB; 138 measured no better): with the 12-KB stack, seven workgroups of k_extend fit the CU's 160 KB of LDS
+#define MI_Q_PAD 2           // codes a quantised plane is moved outward beyond its rounding
+#define MI_Q_SEL_LO 0x0701000cu // v_perm_b32 selectors {0x3F, code byte 1, code byte 0, 0x00} of the low / high half
+#define MI_Q_SEL_HI 0x0703020cu
+#define MI_Q_SEL_FLIP 0x00020200u
 #define MI_TREELET_LEVELS 4  // root + up to four levels below it, breadth first
 
 struct f3 {
@@ -59,9 +69,13 @@ __device__ __forceinline__ f3 operator-(f3 a, f3 b) { return f3{a.x - b.x, a.y -
 __device__ __forceinline__ f3 operator-(f3 a) { return f3{-a.x, -a.y, -a.z}; }
 __device__ __forceinline__ f3 operator*(f3 a, float f) { return f3{a.x * f, a.y * f, a.z * f}; }
 __device__ __forceinline__ f3 operator*(float f, f3 a) { return f3{f * a.x, f * a.y, f * a.z}; }
-// vec.h:188-190 sums lanes left to right; the w*w product is +0 and adding it
-// changes nothing (only the sign of an exact zero sum, which no test observes).
+// vec.h:188-190 sums four lanes left to right; positions and directions carry w = 0, so the
+// fourth product is a zero and adding it changes nothing but the sign of an exact zero sum
+// (-0 + +0 = +0).  dot3 leaves it out; dot3w adds the +0 where that sign is observable: the
+// plane distances of the triangle test, whose quotient is -0 / +0 / +-inf for a ray that
+// starts on, or lies in, the triangle's plane.
 __device__ __forceinline__ float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ float dot3w(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z + 0.0f; }
 __device__ __forceinline__ f3 cross3(f3 a, f3 b) { // vec.h:204-208
     return f3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
 }
@@ -295,8 +309,8 @@ __device__ __forceinline__ void tri_test(const DevScene &sc, int slot, f3 o, f3 
     const char *rec = (const char *)sc.tri + ((uint32_t)slot << 6);
     float4 v0 = *(const float4 *)(rec), ui = *(const float4 *)(rec + 16), vi = *(const float4 *)(rec + 32), ni = *(const float4 *)(rec + 48);
     f3 p = o - xyz(v0);
-    float pz = dot3(xyz(ni), p);
-    float dz = dot3(xyz(ni), d);
+    float pz = dot3w(xyz(ni), p);
+    float dz = dot3w(xyz(ni), d);
     float t = -pz / dz;
     f3 hit = p + t * d;
     float u = dot3(xyz(ui), hit);
@@ -329,26 +343,9 @@ __device__ __forceinline__ void prim_test(const DevScene &sc, int slot, f3 o, f3
     else tri_test(sc, slot, o, d, h);
 }
 
-// bbox.cu:15-34, the reference's expression: (b - p) * (1/d) per slab plane and the
-// `(a<b?a:b)` macros (a NaN operand yields the second operand).  Used for rays with a
-// zero / denormal direction component (1/d infinite or huge), where NaNs can arise.
-__device__ __forceinline__ bool slab_exact(f3 bmin, f3 bmax, f3 o, f3 inv, float tmax, float &tmin_out) {
-    float t10 = (bmin.x - o.x) * inv.x, t11 = (bmin.y - o.y) * inv.y, t12 = (bmin.z - o.z) * inv.z;
-    float t20 = (bmax.x - o.x) * inv.x, t21 = (bmax.y - o.y) * inv.y, t22 = (bmax.z - o.z) * inv.z;
-    float tmin = -1.0e38f;
-#define MI_MIN(a, b) ((a) < (b) ? (a) : (b))
-#define MI_MAX(a, b) ((a) < (b) ? (b) : (a))
-    tmin = MI_MAX(tmin, MI_MIN(t10, t20));
-    tmin = MI_MAX(tmin, MI_MIN(t11, t21));
-    tmin = MI_MAX(tmin, MI_MIN(t12, t22));
-    tmax = MI_MIN(tmax, MI_MAX(t10, t20));
-    tmax = MI_MIN(tmax, MI_MAX(t11, t21));
-    tmax = MI_MIN(tmax, MI_MAX(t12, t22));
-#undef MI_MIN
-#undef MI_MAX
-    tmin_out = tmin;
-    return tmin <= tmax && tmax > 0;
-}
+// The slab test (bbox.cu:15-34 in the reference: (b - p) * (1/d) per plane, `(a<b?a:b)` min/max)
+// is a culling test: any test that accepts every box the closest primitive lies in leads to the
+// same hit.  The kernels run slab_fast_q below on quantised, outward-rounded planes.
 
 // Raw VALU min/max (no sNaN-canonicalising v_max x,x in front of every operand, which
 // hipcc adds to fminf/fmaxf).  Only used where no operand can be NaN.
@@ -357,17 +354,28 @@ __device__ __forceinline__ float vmax(float a, float b) { float r; asm("v_max_f3
 __device__ __forceinline__ float vmin3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 __device__ __forceinline__ float vmax3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 
-// Fast slab test for rays whose 1/d is finite and moderate on every axis (no NaN can
-// arise): one FMA per plane, t = b*(1/d) - o*(1/d), and hardware min/max.  It brackets
-// the same interval as bbox.cu:21-32 up to rounding of the order of one ulp of the
-// coordinates, far inside the 1e-5 x scene-diagonal padding of the stored boxes, so it
-// is a conservative culling test: the closest hit it leads to is the one a test of
-// every primitive finds (checked bit-for-bit against the brute-force oracle).
-__device__ __forceinline__ bool slab_fast(f3 bmin, f3 bmax, f3 inv, f3 noi, float tmax, float &tmin_out) {
-    float t10 = __builtin_fmaf(bmin.x, inv.x, noi.x), t11 = __builtin_fmaf(bmin.y, inv.y, noi.y), t12 = __builtin_fmaf(bmin.z, inv.z, noi.z);
-    float t20 = __builtin_fmaf(bmax.x, inv.x, noi.x), t21 = __builtin_fmaf(bmax.y, inv.y, noi.y), t22 = __builtin_fmaf(bmax.z, inv.z, noi.z);
-    float tmin = vmax3(vmin(t10, t20), vmin(t11, t21), vmin(t12, t22));
-    float tmx = vmin(tmax, vmin3(vmax(t10, t20), vmax(t11, t21), vmax(t12, t22)));
+// Plane code -> its float F (one v_perm_b32: byte 3 from the constant, bytes 2..1 the code, byte 0 zero).
+__device__ __forceinline__ float q_code(uint32_t packed, uint32_t sel) {
+    return __uint_as_float(__builtin_amdgcn_perm(0x3F000000u, packed, sel));
+}
+// Slab test on the quantised planes.  The ray carries, per axis, ia = qs/d and ic = (qb - o)/d, so the distance to the
+// plane of code F is ONE FMA, F*ia + ic; and it carries the v_perm selector of its NEAR
+// plane (the lower one when d > 0, the upper one when d < 0), so near and far planes are
+// decoded directly and the per-axis min/max of bbox.cu:21-32 disappears: six v_perm take
+// the place of six v_min/v_max, and a node is 64 B instead of 128.  The interval is the
+// reference's up to rounding of a few ulp of the scene extent, far inside the outward
+// rounding of the codes (MI_Q_PAD steps of extent/98304 or /49152) and the 1e-5 x
+// scene-diagonal padding of the boxes they were made from: a conservative culling test,
+// so the closest hit it leads to is the one a test of every primitive finds (checked
+// bit-for-bit against the brute-force oracle).
+__device__ __forceinline__ bool slab_fast_q(uint32_t px, uint32_t py, uint32_t pz, const uint32_t seln[3], const uint32_t self[3], f3 ia,
+                                            f3 ic, float tmax, float &tmin_out) {
+    const float n0 = __builtin_fmaf(q_code(px, seln[0]), ia.x, ic.x), n1 = __builtin_fmaf(q_code(py, seln[1]), ia.y, ic.y),
+                n2 = __builtin_fmaf(q_code(pz, seln[2]), ia.z, ic.z);
+    const float f0 = __builtin_fmaf(q_code(px, self[0]), ia.x, ic.x), f1 = __builtin_fmaf(q_code(py, self[1]), ia.y, ic.y),
+                f2 = __builtin_fmaf(q_code(pz, self[2]), ia.z, ic.z);
+    const float tmin = vmax3(n0, n1, n2);
+    const float tmx = vmin(tmax, vmin3(f0, f1, f2));
     tmin_out = tmin;
     return tmin <= tmx && tmx > 0;
 }
@@ -383,19 +391,26 @@ __device__ __forceinline__ bool tail_took_over(const uint32_t *tail_level, int l
 #define MI_NONE (-1)
 // Per-lane traversal state of the persistent kernels.
 struct Lane {
-    f3 o, d, inv, noi; // noi = -(o * inv), for the fast slab test
+    f3 o, d;
+    f3 ia, ic;        // fast slab test: distance to the plane of code F on axis a = F * ia.a + ic.a
+    uint32_t seln[3]; // v_perm selector of the near plane on each axis
     Hit h;
     int cur, sp; // cur: >= 0 node to visit, < 0 leaf ~cur to test, MI_DONE finished
-    bool exact;
 };
 __device__ __forceinline__ void lane_start(const DevScene &sc, Lane &L, f3 o, f3 d, float t0 = MI_NO_HIT) {
     L.o = o;
     L.d = d;
-    L.inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z); // ray.h:53-57,79-82
-    L.noi = mk3(-(o.x * L.inv.x), -(o.y * L.inv.y), -(o.z * L.inv.z));
-    // fast slab path only when nothing can overflow to inf/NaN (the comparisons are false for NaN)
-    L.exact = !(__builtin_fabsf(L.inv.x) < 1e30f && __builtin_fabsf(L.inv.y) < 1e30f && __builtin_fabsf(L.inv.z) < 1e30f &&
-                __builtin_fabsf(L.noi.x) < 1e30f && __builtin_fabsf(L.noi.y) < 1e30f && __builtin_fabsf(L.noi.z) < 1e30f);
+    // 1/d as in ray.h:53-57,79-82, clamped to +-1e18: an axis-parallel ray (d = +-0, 1/d = +-inf) is
+    // culled like one that drifts by 1e-18 per unit of t — less than a billionth of the box padding over
+    // any distance a hit can have — and every product below stays finite (coordinates are < 1e15), so
+    // no inf - inf or 0 * inf can arise in the slab test.
+    const f3 inv = mk3(__builtin_amdgcn_fmed3f(1.0f / d.x, -1e18f, 1e18f), __builtin_amdgcn_fmed3f(1.0f / d.y, -1e18f, 1e18f),
+                       __builtin_amdgcn_fmed3f(1.0f / d.z, -1e18f, 1e18f));
+    L.ia = mk3(sc.qs[0] * inv.x, sc.qs[1] * inv.y, sc.qs[2] * inv.z);
+    L.ic = mk3((sc.qb[0] - o.x) * inv.x, (sc.qb[1] - o.y) * inv.y, (sc.qb[2] - o.z) * inv.z);
+    L.seln[0] = inv.x < 0.0f ? MI_Q_SEL_HI : MI_Q_SEL_LO;
+    L.seln[1] = inv.y < 0.0f ? MI_Q_SEL_HI : MI_Q_SEL_LO;
+    L.seln[2] = inv.z < 0.0f ? MI_Q_SEL_HI : MI_Q_SEL_LO;
     L.h = Hit{t0, 0.0f, 0.0f, -1};
     L.sp = 0;
     // bvh.cu:174-176,180-183: nothing to hit / a single primitive / a tree
@@ -431,32 +446,22 @@ __device__ __forceinline__ void cswap(bool sw, float &ka, float &kb, int &ra, in
     const int r0 = sw ? rb : ra, r1 = sw ? ra : rb;
     ka = k0; kb = k1; ra = r0; rb = r1;
 }
-__device__ __forceinline__ void node_phase(const DevScene &sc, Lane &L, lds_int *stack, int *my_ovf, size_t ovf_stride, const float4 *treelet) {
+__device__ __forceinline__ void node_phase(const DevScene &sc, Lane &L, lds_int *stack, int *my_ovf, size_t ovf_stride, const uint4 *treelet) {
     // one generic (flat) load per 16 B serves both: lanes at the top of the tree read the LDS
     // copy, the others global memory
-    const char *nd = L.cur >= sc.treelet_base ? (const char *)treelet + ((uint32_t)(L.cur - sc.treelet_base) << 7)
-                                               : (const char *)sc.nodes + ((uint32_t)L.cur << 7);
-    const float4 lx = *(const float4 *)(nd), ly = *(const float4 *)(nd + 16), lz = *(const float4 *)(nd + 32);
-    const float4 hx = *(const float4 *)(nd + 48), hy = *(const float4 *)(nd + 64), hz = *(const float4 *)(nd + 80);
-    const int4 refs = *(const int4 *)(nd + 96);
-    const float LX[4] = {lx.x, lx.y, lx.z, lx.w}, LY[4] = {ly.x, ly.y, ly.z, ly.w}, LZ[4] = {lz.x, lz.y, lz.z, lz.w};
-    const float HX[4] = {hx.x, hx.y, hx.z, hx.w}, HY[4] = {hy.x, hy.y, hy.z, hy.w}, HZ[4] = {hz.x, hz.y, hz.z, hz.w};
+    const char *nd = L.cur >= sc.treelet_base ? (const char *)treelet + ((uint32_t)(L.cur - sc.treelet_base) << 6)
+                                               : (const char *)sc.qnodes + ((uint32_t)L.cur << 6);
+    const uint4 px = *(const uint4 *)(nd), py = *(const uint4 *)(nd + 16), pz = *(const uint4 *)(nd + 32);
+    const int4 refs = *(const int4 *)(nd + 48);
+    const uint32_t PX[4] = {px.x, px.y, px.z, px.w}, PY[4] = {py.x, py.y, py.z, py.w}, PZ[4] = {pz.x, pz.y, pz.z, pz.w};
     int R[4] = {refs.x, refs.y, refs.z, refs.w};
     float K[4]; // entry distance of a child that is hit, +inf otherwise
-    if (L.exact) {
+    const uint32_t self[3] = {L.seln[0] ^ MI_Q_SEL_FLIP, L.seln[1] ^ MI_Q_SEL_FLIP, L.seln[2] ^ MI_Q_SEL_FLIP};
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
-            float tmin;
-            const bool hit = slab_exact(mk3(LX[c], LY[c], LZ[c]), mk3(HX[c], HY[c], HZ[c]), L.o, L.inv, L.h.t, tmin);
-            K[c] = (hit && R[c] != MI_DONE) ? tmin : __builtin_inff();
-        }
-    } else {
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-            float tmin;
-            const bool hit = slab_fast(mk3(LX[c], LY[c], LZ[c]), mk3(HX[c], HY[c], HZ[c]), L.inv, L.noi, L.h.t, tmin);
-            K[c] = (hit && R[c] != MI_DONE) ? tmin : __builtin_inff();
-        }
+    for (int c = 0; c < 4; c++) {
+        float tmin;
+        const bool hit = slab_fast_q(PX[c], PY[c], PZ[c], L.seln, self, L.ia, L.ic, L.h.t, tmin);
+        K[c] = (hit && R[c] != MI_DONE) ? tmin : __builtin_inff();
     }
     // sorting network, descending by entry distance: K[0] farthest ... K[3] nearest
     cswap(K[0] < K[1], K[0], K[1], R[0], R[1]);
@@ -515,8 +520,8 @@ k_extend(DevScene sc, const uint32_t *count_ptr, uint32_t fixed_count, uint32_t 
          const uint32_t *tail_level, int level) {
     __shared__ int lds_stack[MI_LDS_STACK * MI_BLOCK];
     if (!PRIMARY && tail_level && tail_took_over(tail_level, level)) return;
-    __shared__ float4 lds_treelet[MI_TREELET * 8];
-    for (int i = threadIdx.x; i < sc.treelet_count * 8; i += MI_BLOCK) lds_treelet[i] = sc.nodes[(size_t)sc.treelet_base * 8 + i];
+    __shared__ uint4 lds_treelet[MI_TREELET * 4];
+    for (int i = threadIdx.x; i < sc.treelet_count * 4; i += MI_BLOCK) lds_treelet[i] = sc.qnodes[(size_t)sc.treelet_base * 4 + i];
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
@@ -541,9 +546,10 @@ k_extend(DevScene sc, const uint32_t *count_ptr, uint32_t fixed_count, uint32_t 
     bool active = false;
     uint32_t slot = 0;
     Lane L;
-    L.cur = MI_DONE; L.sp = 0; L.exact = false;
+    L.cur = MI_DONE; L.sp = 0;
     L.h = Hit{MI_NO_HIT, 0.0f, 0.0f, -1};
-    L.o = L.d = L.inv = L.noi = mk3(0, 0, 0);
+    L.o = L.d = L.ia = L.ic = mk3(0, 0, 0);
+    L.seln[0] = L.seln[1] = L.seln[2] = MI_Q_SEL_LO;
     unsigned long long act = 0ull; // ballot of `active`
     // Level 0: the camera rays of a chunk are computed by all 64 lanes at once when the wave
     // takes the chunk, and parked in LDS until the refills hand them out.  (Computed inside
@@ -636,10 +642,6 @@ k_extend(DevScene sc, const uint32_t *count_ptr, uint32_t fixed_count, uint32_t 
             if (COUNT) {
                 n_nodes++;
                 ray_steps++;
-#ifdef MI_DEPTH_HISTOGRAM // visits per tree level (slow: contended atomics); used once to size an LDS treelet
-                int depth = __float_as_int(sc.nodes[8 * (size_t)L.cur + 7].x);
-                atomicAdd(&work_stats[8 + (depth < 40 ? depth : 39)], 1ull);
-#endif
             }
             node_phase(sc, L, stack, my_ovf, ovf_stride, lds_treelet);
         }
@@ -939,8 +941,8 @@ k_tail(DevScene sc, ShardGeom g, uint32_t pix0, uint32_t npix, int level0, int d
     const uint32_t tl = *tail_level;
     // same decision in every wave: tl is only ever written with level0 by this launch
     if (n == 0 || n > threshold || (tl != 0 && tl != (uint32_t)level0)) return;
-    __shared__ float4 lds_treelet[MI_TREELET * 8];
-    for (int i = threadIdx.x; i < sc.treelet_count * 8; i += MI_BLOCK) lds_treelet[i] = sc.nodes[(size_t)sc.treelet_base * 8 + i];
+    __shared__ uint4 lds_treelet[MI_TREELET * 4];
+    for (int i = threadIdx.x; i < sc.treelet_count * 4; i += MI_BLOCK) lds_treelet[i] = sc.qnodes[(size_t)sc.treelet_base * 4 + i];
     __syncthreads();
     const int lane = threadIdx.x & 63;
     if (blockIdx.x == 0 && threadIdx.x == 0) *tail_level = (uint32_t)level0;
@@ -959,9 +961,10 @@ k_tail(DevScene sc, ShardGeom g, uint32_t pix0, uint32_t npix, int level0, int d
     int level = level0;
     float4 T = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     Lane L;
-    L.cur = MI_DONE; L.sp = 0; L.exact = false;
+    L.cur = MI_DONE; L.sp = 0;
     L.h = Hit{MI_NO_HIT, 0.0f, 0.0f, -1};
-    L.o = L.d = L.inv = L.noi = mk3(0, 0, 0);
+    L.o = L.d = L.ia = L.ic = mk3(0, 0, 0);
+    L.seln[0] = L.seln[1] = L.seln[2] = MI_Q_SEL_LO;
     unsigned long long act = 0ull;
     bool more = true; // wave-uniform
     do {              // single back edge, no `continue` (see k_extend)

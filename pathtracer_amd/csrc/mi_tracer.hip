@@ -61,7 +61,7 @@ struct mi_ctx {
     DevScene sc{};
     uint32_t n_nodes = 0;   // of the binary tree kept in `nodes` (download, quality); the kernels walk `nodes4`
     int32_t root_ref2 = ~0;
-    DevBuf nodes, nodes4, tri, tri_normal, tri_mat, tri_has_vmat, sph, sph_mat, mats, prim_id, cube;
+    DevBuf nodes, nodes4, qnodes, tri, tri_normal, tri_mat, tri_has_vmat, sph, sph_mat, mats, prim_id, cube;
     // per-batch path state (sized by slot capacity / depth): two ray streams (level k reads
     // stream k&1 and writes stream (k+1)&1), hits by stream position, history and path value by slot
     DevBuf ray_o[2], ray_d[2], thr[2], hits, path_out, hist, counters, ovf, totals;
@@ -153,7 +153,7 @@ MI_API void mi_ctx_destroy(mi_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    DevBuf *all[] = {&c->nodes, &c->nodes4, &c->tri, &c->tri_normal, &c->tri_mat, &c->tri_has_vmat, &c->sph, &c->sph_mat, &c->mats,
+    DevBuf *all[] = {&c->nodes, &c->nodes4, &c->qnodes, &c->tri, &c->tri_normal, &c->tri_mat, &c->tri_has_vmat, &c->sph, &c->sph_mat, &c->mats,
                      &c->prim_id, &c->cube, &c->ray_o[0], &c->ray_o[1], &c->ray_d[0], &c->ray_d[1], &c->thr[0], &c->thr[1], &c->hits,
                      &c->path_out, &c->hist, &c->counters, &c->ovf, &c->totals, &c->out_mean, &c->out_rgba8,
                      &c->out_rgb8, &c->out_mean_frame, &c->probe_i, &c->probe_t, &c->probe_n};
@@ -168,6 +168,8 @@ MI_API void mi_ctx_destroy(mi_ctx *c) {
 // range, every primitive slot referenced exactly once, depth <= MI_MAX_STACK.
 static mi_status validate_prims(const mi_scene_soa *s) {
     const uint64_t n_prim = (uint64_t)s->n_tri + s->n_sph;
+    for (int k = 0; k < 3; k++) // the slab test's products stay finite for coordinates below 1e15 (lane_start)
+        if (!(s->cam_eye[k] > -1e15f && s->cam_eye[k] < 1e15f)) return fail(MI_ERR_INVALID, "scene: camera position not finite or huge");
     if (n_prim == 0) return MI_OK;
     if (!s->prim_id || !s->materials || s->n_mat == 0) return fail(MI_ERR_INVALID, "scene: prim_id/materials missing");
     if (s->n_tri && !(s->tri_v0 && s->tri_uinv && s->tri_vinv && s->tri_ninv && s->tri_normal && s->tri_mat && s->tri_has_vmat))
@@ -328,6 +330,38 @@ static mi_status upload_prims(mi_ctx *c, const mi_scene_soa *s) {
     return MI_OK;
 }
 
+// Last step of every upload: the fp32 4-wide nodes in c->nodes4 (the tree and the treelet copies behind
+// it, n_total nodes, root c->sc.root_ref) -> the 64-B quantised nodes the kernels read.  The code grid
+// spans the root's box (the union of its seats): F = 0.51 at its lower face, 1.99 at its upper face.
+static mi_status quantize_nodes4(mi_ctx *c, uint32_t n_total) {
+    c->sc.qnodes = nullptr;
+    for (int a = 0; a < 3; a++) { c->sc.qs[a] = 1.0f; c->sc.qb[a] = 0.0f; }
+    const int32_t root = c->sc.root_ref;
+    if (n_total == 0 || root < 0 || root == MI_DONE || (uint32_t)root >= n_total) return MI_OK; // no interior node: nothing walks qnodes
+    float rn[32];
+    HIPCHK(hipMemcpy(rn, c->nodes4.as<float>() + 32 * (size_t)root, 128, hipMemcpyDeviceToHost));
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int k = 0; k < 4; k++) {
+        int32_t r;
+        memcpy(&r, &rn[24 + k], 4);
+        if (r == MI_DONE) continue;
+        for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], rn[4 * a + k]); hi[a] = std::max(hi[a], rn[12 + 4 * a + k]); }
+    }
+    for (int a = 0; a < 3; a++) {
+        float ext = hi[a] - lo[a];
+        if (!(ext > 0.0f) || !std::isfinite(ext)) { ext = 1.0f; if (!std::isfinite(lo[a])) lo[a] = 0.0f; }
+        c->sc.qs[a] = ext / 1.48f;
+        c->sc.qb[a] = lo[a] - 0.51f * c->sc.qs[a];
+    }
+    HIPCHK(c->qnodes.ensure((size_t)n_total * 64));
+    hipLaunchKernelGGL(k_quantize_nodes4, dim3((n_total + 255) / 256), dim3(256), 0, c->stream, c->nodes4.as<float>(), (int)n_total, c->sc.qs[0],
+                       c->sc.qs[1], c->sc.qs[2], c->sc.qb[0], c->sc.qb[1], c->sc.qb[2], (int)MI_DONE, c->qnodes.as<uint4>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->sc.qnodes = c->qnodes.as<uint4>();
+    return MI_OK;
+}
+
 // Collapses the binary tree (host copy) into the 4-wide tree the kernels walk and uploads it.
 static mi_status install_bvh4(mi_ctx *c, const float *nodes2, int32_t root2) {
     std::vector<float> n4;
@@ -363,9 +397,8 @@ static mi_status install_bvh4(mi_ctx *c, const float *nodes2, int32_t root2) {
     }
     HIPCHK(c->nodes4.ensure(std::max<size_t>(n4.size() * 4, 16)));
     if (!n4.empty()) HIPCHK(hipMemcpy(c->nodes4.p, n4.data(), n4.size() * 4, hipMemcpyHostToDevice));
-    c->sc.nodes = c->nodes4.as<float4>();
     c->sc.root_ref = root4;
-    return MI_OK;
+    return quantize_nodes4(c, (uint32_t)(n4.size() / 32));
 }
 
 MI_API mi_status mi_scene_upload(mi_ctx *c, const mi_scene_soa *s) {
@@ -455,7 +488,7 @@ MI_API mi_status mi_scene_upload_build(mi_ctx *c, const mi_scene_soa *s, const f
     HIPCHK(hipSetDevice(c->device));
     mi_status us = upload_prims(c, s);
     if (us != MI_OK) return us;
-    c->sc.nodes = nullptr;
+    c->sc.qnodes = nullptr;
     c->n_nodes = 0;
     if (n <= 1) { // no interior node: bvh.cu:174-183
         HIPCHK(c->nodes.ensure(16));
@@ -630,10 +663,11 @@ MI_API mi_status mi_scene_upload_build(mi_ctx *c, const mi_scene_soa *s, const f
     if (rs != MI_OK) return rs;
     c->root_ref2 = root2;
     c->n_nodes = n - 1;
-    c->sc.nodes = c->nodes4.as<float4>(); // collapsed on the device above
-    c->sc.root_ref = root4;
+    c->sc.root_ref = root4; // collapsed on the device above
     c->sc.treelet_base = (int32_t)n4;
     c->sc.treelet_count = treelet_n;
+    mi_status qs = quantize_nodes4(c, n4 + (uint32_t)treelet_n);
+    if (qs != MI_OK) return qs;
     c->has_scene = true;
     return MI_OK;
 }
