@@ -416,11 +416,13 @@ __global__ void k_build_treelet(float *nodes4, int root4, int base, int max_node
 // nodes the traversal kernels read (DevScene::qnodes).  One thread per node.  A plane b on axis a
 // becomes n = (b - qb[a]) / qs[a], which the caller's choice of qs, qb keeps inside [0.51, 1.99]
 // for every plane inside the scene box; the code is bits 23..8 of the float n rounded DOWN for a
-// lower plane and UP for an upper plane, then moved MI_Q_PAD codes further out.  Planes outside
+// lower plane and UP for an upper plane after moving it MI_Q_MARGIN (a quarter or an eighth of a code
+// step; ~2e-6 of the scene extent, an order of magnitude above the slab test's rounding for ray origins
+// within a few extents of the scene) and MI_Q_PAD whole codes outward.  Planes outside
 // the scene box are clamped to it (what lies outside the root's box cannot be reached anyway).
 // Empty seats get an inverted box.
 __device__ __forceinline__ uint32_t q_encode(float b, float qs, float qb, bool upper) {
-    double n = ((double)b - (double)qb) / (double)qs;
+    double n = ((double)b - (double)qb) / (double)qs + (upper ? MI_Q_MARGIN : -MI_Q_MARGIN);
     n = n < 0.5 ? 0.5 : (n > 1.999 ? 1.999 : n);
     const float f = upper ? __double2float_ru(n) : __double2float_rd(n);
     const uint32_t m = __float_as_uint(f) - 0x3F000000u; // 24 bits: [0.5, 2) is two binades

@@ -31,7 +31,7 @@ struct DevScene {
     // the two planes of seat c on that axis as 16-bit codes (low half: lower plane, high half: upper
     // plane).  A code q stands for the float F with bits 0x3F000000 | q << 8, a number in [0.5, 2)
     // (two binades, 15 mantissa bits), and for the plane qs[a] * F + qb[a].  Codes are rounded outward
-    // by MI_Q_PAD steps, so a quantised box encloses the fp32 box it was made from.
+    // (q_encode in mi_bvh_build.h), so a quantised box encloses the fp32 box it was made from.
     const uint4 *qnodes;
     float qs[3], qb[3];
     const float4 *tri;   // 4 x float4 per triangle slot: v0, uInv, vInv, nInv
@@ -53,7 +53,8 @@ struct DevScene {
     int32_t treelet_base, treelet_count;
 };
 #define MI_TREELET 69        // nodes (4.4 KB; 138 measured no better): with the 12-KB stack, seven workgroups of k_extend fit the CU's 160 KB of LDS
-#define MI_Q_PAD 2           // codes a quantised plane is moved outward beyond its rounding
+#define MI_Q_PAD 0           // whole codes a quantised plane is moved outward beyond its rounding
+#define MI_Q_MARGIN 3.814697265625e-06 // 2^-18: what a plane is moved outward (in F) before it is rounded outward
 #define MI_Q_SEL_LO 0x0701000cu // v_perm_b32 selectors {0x3F, code byte 1, code byte 0, 0x00} of the low / high half
 #define MI_Q_SEL_HI 0x0703020cu
 #define MI_Q_SEL_FLIP 0x00020200u
@@ -364,7 +365,7 @@ __device__ __forceinline__ float q_code(uint32_t packed, uint32_t sel) {
 // decoded directly and the per-axis min/max of bbox.cu:21-32 disappears: six v_perm take
 // the place of six v_min/v_max, and a node is 64 B instead of 128.  The interval is the
 // reference's up to rounding of a few ulp of the scene extent, far inside the outward
-// rounding of the codes (MI_Q_PAD steps of extent/98304 or /49152) and the 1e-5 x
+// rounding of the codes (steps of extent/98304 or /49152) and the 1e-5 x
 // scene-diagonal padding of the boxes they were made from: a conservative culling test,
 // so the closest hit it leads to is the one a test of every primitive finds (checked
 // bit-for-bit against the brute-force oracle).
