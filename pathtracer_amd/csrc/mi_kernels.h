@@ -462,7 +462,7 @@ __device__ __forceinline__ void node_phase(const DevScene &sc, Lane &L, lds_int 
     for (int c = 0; c < 4; c++) {
         float tmin;
         const bool hit = slab_fast_q(PX[c], PY[c], PZ[c], L.seln, self, L.ia, L.ic, L.h.t, tmin);
-        K[c] = (hit && R[c] != MI_DONE) ? tmin : __builtin_inff();
+        K[c] = hit ? tmin : __builtin_inff(); // an empty seat's box is inverted on every axis: never hit
     }
     // sorting network, descending by entry distance: K[0] farthest ... K[3] nearest
     cswap(K[0] < K[1], K[0], K[1], R[0], R[1]);
