@@ -473,7 +473,22 @@ __device__ __forceinline__ void node_phase(const DevScene &sc, Lane &L, lds_int 
     // children that are not hit have K = +inf and sort to the front; push the hit ones of
     // K[0..2] (farthest first), continue with K[3] if it is hit, else pop
     const float inf = __builtin_inff();
-    if (K[3] < inf) {
+    if (__builtin_amdgcn_ballot_w64(L.sp > MI_LDS_STACK - 3) == 0ull) {
+        // Nobody in the wave can run out of LDS stack here: the three candidates are STORED
+        // unconditionally — the slot above the top of a stack is free, so a ref that is not
+        // pushed does no harm there — and only the stack pointer moves conditionally.  No
+        // branch per push.  (If K[3] is not hit, nothing is: the pointer stays.)
+        int sp = L.sp;
+        stack[sp * MI_BLOCK] = R[0];
+        sp += K[0] < inf ? 1 : 0;
+        stack[sp * MI_BLOCK] = R[1];
+        sp += K[1] < inf ? 1 : 0;
+        stack[sp * MI_BLOCK] = R[2];
+        sp += K[2] < inf ? 1 : 0;
+        L.sp = sp;
+        if (K[3] < inf) L.cur = R[3];
+        else lane_pop(L, stack, my_ovf, ovf_stride);
+    } else if (K[3] < inf) {
         if (K[0] < inf) lane_push(L, stack, my_ovf, ovf_stride, R[0]);
         if (K[1] < inf) lane_push(L, stack, my_ovf, ovf_stride, R[1]);
         if (K[2] < inf) lane_push(L, stack, my_ovf, ovf_stride, R[2]);
