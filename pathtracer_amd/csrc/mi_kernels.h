@@ -948,7 +948,7 @@ k_shade(DevScene sc, ShardGeom g, uint32_t pix0, uint32_t npix, int level, int d
 // k_extend plus a shade phase, and is refilled from the queue when its path ends.  It
 // then publishes its level in *tail_level so the per-level kernels behind it return
 // immediately.  Rays traced beyond the first level are added to *extra_rays.
-__global__ void __launch_bounds__(MI_BLOCK)
+__global__ void __launch_bounds__(MI_BLOCK, 5)
 k_tail(DevScene sc, ShardGeom g, uint32_t pix0, uint32_t npix, int level0, int depth_total, uint64_t seed, RayStream in,
        const uint32_t *count_ptr, uint32_t threshold, uint32_t *tail_level, float4 *hist, size_t cap, float4 *path_out, int *ovf,
        unsigned long long *extra_rays, int leaf_min, int shade_min) {
