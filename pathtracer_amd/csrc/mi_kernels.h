@@ -401,12 +401,14 @@ struct Lane {
 __device__ __forceinline__ void lane_start(const DevScene &sc, Lane &L, f3 o, f3 d, float t0 = MI_NO_HIT) {
     L.o = o;
     L.d = d;
-    // 1/d as in ray.h:53-57,79-82, clamped to +-1e18: an axis-parallel ray (d = +-0, 1/d = +-inf) is
-    // culled like one that drifts by 1e-18 per unit of t — less than a billionth of the box padding over
-    // any distance a hit can have — and every product below stays finite (coordinates are < 1e15), so
-    // no inf - inf or 0 * inf can arise in the slab test.
-    const f3 inv = mk3(__builtin_amdgcn_fmed3f(1.0f / d.x, -1e18f, 1e18f), __builtin_amdgcn_fmed3f(1.0f / d.y, -1e18f, 1e18f),
-                       __builtin_amdgcn_fmed3f(1.0f / d.z, -1e18f, 1e18f));
+    // 1/d (ray.h:53-57,79-82) feeds only the slab test, a culling test with margins (slab_fast_q), so
+    // the hardware reciprocal (v_rcp_f32, 1 ulp) replaces three IEEE divisions: it scales every plane
+    // distance of the ray by the same 1 +- 1e-7.  Clamped to +-1e18: an axis-parallel ray (d = +-0,
+    // 1/d = +-inf) is culled like one that drifts by 1e-18 per unit of t — less than a billionth of
+    // the box padding over any distance a hit can have — and every product below stays finite
+    // (coordinates are < 1e15), so no inf - inf or 0 * inf can arise in the slab test.
+    const f3 inv = mk3(__builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(d.x), -1e18f, 1e18f), __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(d.y), -1e18f, 1e18f),
+                       __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(d.z), -1e18f, 1e18f));
     L.ia = mk3(sc.qs[0] * inv.x, sc.qs[1] * inv.y, sc.qs[2] * inv.z);
     L.ic = mk3((sc.qb[0] - o.x) * inv.x, (sc.qb[1] - o.y) * inv.y, (sc.qb[2] - o.z) * inv.z);
     L.seln[0] = inv.x < 0.0f ? MI_Q_SEL_HI : MI_Q_SEL_LO;
