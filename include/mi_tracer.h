@@ -177,6 +177,16 @@ mi_status mi_scene_quality(mi_ctx *ctx, double *sah_cost_out);
 mi_status mi_scene_download_nodes(mi_ctx *ctx, float *nodes_out, uint32_t capacity_nodes,
                                   uint32_t *n_nodes_out, int32_t *root_ref_out);
 
+/* Copy the tree the kernels actually walk, for inspection and tests: per 4-wide node (the tree, then the
+ * treelet copies) its 32 fp32 words `lo.x[4] lo.y[4] lo.z[4] hi.x[4] hi.y[4] hi.z[4] refs[4] pad[4]` into
+ * nodes4_out and its 16 quantised words `px[4] py[4] pz[4] refs[4]` into qnodes_out (either may be NULL);
+ * grid_out[0..2] = qs, grid_out[3..5] = qb: the plane of a 16-bit code q on axis a is
+ * qs[a] * F + qb[a] with F the float whose bits are 0x3F000000 | q << 8 (low half of a packed word: lower
+ * plane, high half: upper plane).  n_nodes_out / root_ref_out / treelet_base_out may be NULL.  No
+ * counterpart in the reference. */
+mi_status mi_scene_download_nodes4(mi_ctx *ctx, float *nodes4_out, uint32_t *qnodes_out, uint32_t capacity_nodes,
+                                   uint32_t *n_nodes_out, int32_t *root_ref_out, int32_t *treelet_base_out, float grid_out[6]);
+
 /* prim_id of every slot of the resident scene (the caller's array after mi_scene_upload, the
  * permuted one after mi_scene_upload_build).  No counterpart in the reference. */
 mi_status mi_scene_download_prim_ids(mi_ctx *ctx, int32_t *prim_id_out, uint32_t capacity);

@@ -72,7 +72,7 @@ class BuildStats(C.Structure):
 
 MI_SYMBOLS = [
     "mi_ctx_create", "mi_ctx_destroy", "mi_scene_upload", "mi_scene_upload_build", "mi_scene_quality",
-    "mi_scene_download_nodes", "mi_scene_download_prim_ids", "mi_cubemap_upload", "mi_render", "mi_render_device", "mi_shard_pixels",
+    "mi_scene_download_nodes", "mi_scene_download_nodes4", "mi_scene_download_prim_ids", "mi_cubemap_upload", "mi_render", "mi_render_device", "mi_shard_pixels",
     "mi_assemble_rgb8", "mi_assemble_rgb8_device", "mi_trace_primary", "mi_trace_rays", "mi_occluded_rays", "mi_last_error", "mi_abi_version",
 ]
 
@@ -111,6 +111,9 @@ mi.mi_occluded_rays.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C
 mi.mi_occluded_rays.restype = C.c_int
 mi.mi_scene_upload_build.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(BuildStats)]
 mi.mi_scene_upload_build.restype = C.c_int
+mi.mi_scene_download_nodes4.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_int32),
+                                        C.POINTER(C.c_int32), C.POINTER(C.c_float)]
+mi.mi_scene_download_nodes4.restype = C.c_int
 mi.mi_scene_download_prim_ids.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
 mi.mi_scene_download_prim_ids.restype = C.c_int
 mi.mi_cubemap_upload.argtypes = [C.c_void_p, C.c_void_p]

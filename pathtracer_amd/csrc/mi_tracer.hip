@@ -92,7 +92,7 @@ static const int kCounterWords = (kMaxLevels + 1) * kLevelWords + MI_CNT_STRIDE;
 
 static int extend_grid(const mi_ctx *c) { return c->n_cu * c->extend_wg_per_cu; }
 
-MI_API int mi_abi_version(void) { return 8; }
+MI_API int mi_abi_version(void) { return 9; }
 MI_API const char *mi_last_error(void) { return g_err.c_str(); }
 
 MI_API mi_status mi_ctx_create(int device_id, mi_ctx **out) {
@@ -460,6 +460,23 @@ MI_API mi_status mi_scene_download_nodes(mi_ctx *c, float *nodes_out, uint32_t c
     if (capacity_nodes < c->n_nodes) return fail(MI_ERR_INVALID, "mi_scene_download_nodes: room for %u nodes, tree has %u", capacity_nodes, c->n_nodes);
     HIPCHK(hipSetDevice(c->device));
     if (c->n_nodes) HIPCHK(hipMemcpy(nodes_out, c->nodes.p, (size_t)c->n_nodes * 64, hipMemcpyDeviceToHost));
+    return MI_OK;
+}
+
+MI_API mi_status mi_scene_download_nodes4(mi_ctx *c, float *nodes4_out, uint32_t *qnodes_out, uint32_t capacity_nodes, uint32_t *n_nodes_out,
+                                          int32_t *root_ref_out, int32_t *treelet_base_out, float grid_out[6]) {
+    if (!c) return fail(MI_ERR_INVALID, "mi_scene_download_nodes4: ctx is NULL");
+    if (!c->has_scene) return fail(MI_ERR_NO_SCENE, "mi_scene_download_nodes4: no scene uploaded");
+    const uint32_t n = c->sc.qnodes ? (uint32_t)(c->sc.treelet_base + c->sc.treelet_count) : 0u;
+    if (n_nodes_out) *n_nodes_out = n;
+    if (root_ref_out) *root_ref_out = c->sc.root_ref;
+    if (treelet_base_out) *treelet_base_out = c->sc.treelet_base;
+    if (grid_out) for (int a = 0; a < 3; a++) { grid_out[a] = c->sc.qs[a]; grid_out[3 + a] = c->sc.qb[a]; }
+    if (!nodes4_out && !qnodes_out) return MI_OK;
+    if (capacity_nodes < n) return fail(MI_ERR_INVALID, "mi_scene_download_nodes4: room for %u nodes, tree has %u", capacity_nodes, n);
+    HIPCHK(hipSetDevice(c->device));
+    if (n && nodes4_out) HIPCHK(hipMemcpy(nodes4_out, c->nodes4.p, (size_t)n * 128, hipMemcpyDeviceToHost));
+    if (n && qnodes_out) HIPCHK(hipMemcpy(qnodes_out, c->qnodes.p, (size_t)n * 64, hipMemcpyDeviceToHost));
     return MI_OK;
 }
 

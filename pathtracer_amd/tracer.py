@@ -67,6 +67,19 @@ class Context:
         N.check(N.mi.mi_scene_download_nodes(self._h, nodes.ctypes.data if n.value else None, n.value, C.byref(n), C.byref(root)))
         return nodes, root.value
 
+    def download_nodes4(self):
+        """The tree the kernels walk: (fp32 nodes float32[n,32], quantised nodes uint32[n,16], root_ref,
+        treelet_base, qs float32[3], qb float32[3])."""
+        n, root, tb = C.c_uint32(0), C.c_int32(0), C.c_int32(0)
+        grid = (C.c_float * 6)()
+        N.check(N.mi.mi_scene_download_nodes4(self._h, None, None, 0, C.byref(n), C.byref(root), C.byref(tb), grid))
+        f = np.zeros((n.value, 32), np.float32)
+        q = np.zeros((n.value, 16), np.uint32)
+        if n.value:
+            N.check(N.mi.mi_scene_download_nodes4(self._h, f.ctypes.data, q.ctypes.data, n.value, None, None, None, None))
+        g = np.array(list(grid), np.float32)
+        return f, q, root.value, tb.value, g[:3], g[3:]
+
     def download_prim_ids(self):
         """int32[n_prims]: primitive id of every device slot (permuted by upload_build)."""
         n = self.scene.n_prims

@@ -94,3 +94,46 @@ def test_quantised_nodes_keep_every_hit(ctx, name, text, centre):
         ids, t, nrm = ctx.trace_rays(rays)
         oi, ot, on, _ = O.trace_rays(sc, rays, O.BRUTE)
         assert np.array_equal(ids, oi) and same(t, ot) and same(nrm, on), (name, build)
+
+
+def test_plane_codes_enclose_the_fp32_boxes(ctx, scenes_small):
+    """Structure of the tree the kernels walk (mi_scene_download_nodes4): every quantised box encloses the
+    fp32 box it was made from by at most a code step plus the margin, empty seats are inverted on every
+    axis, refs are carried over, the grid spans the root's box, and the treelet copies equal their
+    originals up to the redirected refs."""
+    MI_DONE = 0x7FFFFFFF
+    for name, build in (("simple", False), ("cornell", False), ("glass", True), ("blob3", False), ("blob3", True)):
+        sc = scenes_small[name]
+        if build:
+            ctx.upload_build(sc)
+        else:
+            ctx.upload(sc)
+        f, q, root, tb, qs, qb = ctx.download_nodes4()
+        n = f.shape[0]
+        assert n > 0 and 0 <= root < n and q.shape == (n, 16)
+        refs = f[:, 24:28].view(np.int32)
+        assert np.array_equal(q[:, 12:16].view(np.int32), refs)
+        lo = f[:, 0:12].reshape(n, 3, 4).astype(np.float64)
+        hi = f[:, 12:24].reshape(n, 3, 4).astype(np.float64)
+        codes = q[:, 0:12].reshape(n, 3, 4)
+        F = lambda c: ((np.uint32(0x3F000000) | (c.astype(np.uint32) << np.uint32(8))).view(np.float32)).astype(np.float64)
+        qlo = F(codes & 0xFFFF) * qs[None, :, None].astype(np.float64) + qb[None, :, None].astype(np.float64)
+        qhi = F(codes >> 16) * qs[None, :, None].astype(np.float64) + qb[None, :, None].astype(np.float64)
+        used = (refs != MI_DONE)[:, None, :].repeat(3, 1)
+        step = qs.astype(np.float64)[None, :, None] * 2.0 ** -15        # the coarser of the two binades
+        assert np.all(qlo[used] <= lo[used]) and np.all(qhi[used] >= hi[used]), name
+        assert np.all((lo - qlo)[used] <= (1.3 * step.repeat(n, 0).repeat(4, 2))[used]) and np.all((qhi - hi)[used] <= (1.3 * step.repeat(n, 0).repeat(4, 2))[used]), name
+        assert np.all((codes[~used] & 0xFFFF) == 0xFFFF) and np.all((codes[~used] >> 16) == 0), name
+        # grid: the root's box maps to F in [0.51, 1.99]
+        r = f[root]
+        rr = r[24:28].view(np.int32) != MI_DONE
+        for a in range(3):
+            rlo, rhi = r[4 * a:4 * a + 4][rr].min(), r[12 + 4 * a:16 + 4 * a][rr].max()
+            assert abs((rlo - qb[a]) / qs[a] - 0.51) < 1e-4 and abs((rhi - qb[a]) / qs[a] - 1.99) < 1e-4, name
+        # treelet copies: boxes equal to some original node's, refs either equal or redirected into the treelet
+        assert 0 < tb <= root < n
+        base = {f[i, :24].tobytes(): i for i in range(tb)}
+        for i in range(tb, n):
+            j = base[f[i, :24].tobytes()]
+            same_or_copy = (refs[i] == refs[j]) | (refs[i] >= tb)
+            assert same_or_copy.all() and np.array_equal(q[i, :12], q[j, :12]), name
