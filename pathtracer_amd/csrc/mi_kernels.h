@@ -560,6 +560,7 @@ k_extend(DevScene sc, const uint32_t *count_ptr, uint32_t fixed_count, uint32_t 
     bool more = chunk < n_chunks;       // wave-uniform: rays may remain for this wave
     uint32_t n_nodes = 0, n_leaves = 0, ray_steps = 0, max_ray_steps = 0, wave_iters = 0;
     uint32_t n_primary = 0; // wave-uniform
+    uint32_t dbg_cnt[7] = {0, 0, 0, 0, 0, 0, 0};
 
     bool active = false;
     uint32_t slot = 0;
@@ -638,6 +639,12 @@ k_extend(DevScene sc, const uint32_t *count_ptr, uint32_t fixed_count, uint32_t 
         const bool want_leaf = active && L.cur < 0;
         const bool want_node = active && L.cur >= 0 && L.cur != MI_DONE;
         const int nl = __popcll(__ballot(want_leaf)), nn = __popcll(__ballot(want_node));
+        if (COUNT && lane == 0) { // lane slots of this iteration by state (instrumented variant only)
+            const bool leaf_it = !more ? false : (nl > 0 && (nl >= leaf_min || nn == 0));
+            if (!more) { dbg_cnt[3] += (uint32_t)(64 - nl - nn); dbg_cnt[4] += (uint32_t)(nl + nn); }   // draining: idle / working
+            else if (leaf_it) { dbg_cnt[0] += (uint32_t)(64 - nl - nn); dbg_cnt[1] += (uint32_t)nn; dbg_cnt[5] += (uint32_t)nl; }  // leaf phase: empty / waiting for node / working
+            else { dbg_cnt[0] += (uint32_t)(64 - nl - nn); dbg_cnt[2] += (uint32_t)nl; dbg_cnt[6] += (uint32_t)nn; }              // node phase: empty / waiting for leaf / working
+        }
         if (!more) {
             // Draining (no rays left to refill with): the wave's remaining time is a latency
             // chain, so every lane advances every iteration, leaves and nodes both.
@@ -674,6 +681,7 @@ k_extend(DevScene sc, const uint32_t *count_ptr, uint32_t fixed_count, uint32_t 
     if (COUNT) {
         atomicMax(&work_stats[2], (unsigned long long)max_ray_steps);
         if (lane == 0) { atomicAdd(&work_stats[3], (unsigned long long)wave_iters); atomicMax(&work_stats[4], (unsigned long long)wave_iters); }
+        if (lane == 0) for (int k = 0; k < 7; k++) atomicAdd(&work_stats[8 + k], (unsigned long long)dbg_cnt[k]);
         atomicAdd(&work_stats[0], (unsigned long long)n_nodes);
         atomicAdd(&work_stats[1], (unsigned long long)n_leaves);
     }

@@ -850,9 +850,11 @@ MI_API mi_status mi_render_device(mi_ctx *c, const mi_render_params *p, void *d_
             fprintf(stderr, "max node steps of one ray %llu, wave iterations total %llu max %llu\n", (unsigned long long)c->h_totals[4],
                     (unsigned long long)c->h_totals[5], (unsigned long long)c->h_totals[6]);
         if (count_work && getenv("MI_TRACER_DEBUG_LEVELS")) {
-            fprintf(stderr, "node visits by tree depth:");
-            for (int dd = 0; dd < 40; dd++) fprintf(stderr, " %llu", (unsigned long long)c->h_totals[10 + dd]);
-            fprintf(stderr, "\n");
+            const char *what[7] = {"no ray (steady)", "node lanes idle in leaf phases", "leaf lanes idle in node phases", "idle while draining", "working while draining",
+                                   "working in leaf phases", "working in node phases"};
+            double tot = 0;
+            for (int dd = 0; dd < 7; dd++) tot += (double)c->h_totals[10 + dd];
+            for (int dd = 0; dd < 7; dd++) fprintf(stderr, "lane slots %-32s %5.1f %%\n", what[dd], 100.0 * (double)c->h_totals[10 + dd] / std::max(tot, 1.0));
         }
         stats->rays_extend = c->h_totals[8];
         if (per_launch) {
