@@ -439,11 +439,11 @@ __device__ __forceinline__ void lane_push(Lane &L, lds_int *stack, int *my_ovf, 
     else my_ovf[(size_t)(L.sp - MI_LDS_STACK) * ovf_stride] = ref;
     L.sp++;
 }
-// Node phase of one lane: fetch the 4-wide node L.cur (128 B: lo.x[4], lo.y[4], lo.z[4],
-// hi.x[4], hi.y[4], hi.z[4], refs[4], pad), slab-test the four child boxes, continue with the
-// nearest child that is hit and push the others, farthest first.  A child ref >= 0 is a node,
-// < 0 a leaf (~slot), MI_DONE an empty seat.  (bvh.cu:178-207 restructured; the 4-wide nodes
-// are collapsed from the caller's binary tree at upload, mi_tracer.hip.)
+// Node phase of one lane: fetch the quantised 4-wide node L.cur (64 B: px[4], py[4], pz[4], refs[4];
+// DevScene::qnodes), slab-test the four child boxes, continue with the nearest child that is hit and
+// push the others, farthest first.  A child ref >= 0 is a node, < 0 a leaf (~slot), MI_DONE an empty
+// seat.  (bvh.cu:178-207 restructured; the 4-wide nodes are collapsed from the caller's binary tree
+// and quantised at upload, mi_tracer.hip.)
 __device__ __forceinline__ void cswap(bool sw, float &ka, float &kb, int &ra, int &rb) {
     const float k0 = sw ? kb : ka, k1 = sw ? ka : kb;
     const int r0 = sw ? rb : ra, r1 = sw ? ra : rb;

@@ -235,7 +235,8 @@ static mi_status get_events(mi_ctx *c, size_t n) {
 
 // The kernels walk a 4-wide tree collapsed from the caller's binary one: a node's seats are
 // its grandchildren (the children of each interior child) or the child itself when that is a
-// leaf.  128 B per node: lo.x[4], lo.y[4], lo.z[4], hi.x[4], hi.y[4], hi.z[4], refs[4], pad.
+// leaf.  This intermediate fp32 form is 128 B per node: lo.x[4], lo.y[4], lo.z[4], hi.x[4], hi.y[4],
+// hi.z[4], refs[4], pad; quantize_nodes4 turns it into the 64-B nodes the kernels read.
 // Refs: >= 0 index of a 4-wide node, < 0 leaf ~slot, MI_DONE empty seat.  `nodes2` has been
 // validated (validate_scene) or was built by this library.  Returns the root ref.
 static int32_t collapse_bvh4(const float *nodes2, int32_t root2, std::vector<float> &out) {
