@@ -221,6 +221,25 @@ __device__ __forceinline__ uint32_t stream_total(const uint32_t *cnt) {
     for (int k = 0; k < MI_SUB; k++) n += cnt[k * MI_CNT_STRIDE];
     return n;
 }
+// Static deal of the virtual chunks over the W persistent waves of a launch: in round k (chunks
+// [kW, (k+1)W)) wave w takes position (w + k*rot) mod W.  rot = 0 is the plain stride-W deal (wave w:
+// w, w+W, ...), which is what every launch uses unless it ALIASES with the period of the slot order:
+// slot = sample * npix + pixel, so with 4096 chunks per sample and W = 6144 every wave of a level-0
+// launch saw only two 8x8 pixel patches, for all of its 171 chunks — waves on the object worked, waves
+// on the sky idled (C4 level 0: VALU 30 % busy, 13.5 ms; 4.8 ms with a rotation).  The host picks rot
+// (deal_rotation in mi_tracer.hip); a rotation costs the 1080p workload 4 % at level 0, hence only then.
+struct ChunkDeal {
+    uint32_t base, pos, rot, w; // all wave-uniform
+};
+__device__ __forceinline__ ChunkDeal deal_start(uint32_t wave_id, uint32_t n_waves, uint32_t rot) {
+    return ChunkDeal{0u, wave_id, rot < n_waves ? rot : 0u, n_waves};
+}
+__device__ __forceinline__ uint32_t deal_chunk(const ChunkDeal &d) { return d.base + d.pos; }
+__device__ __forceinline__ void deal_next(ChunkDeal &d) {
+    d.base += d.w;
+    d.pos += d.rot;
+    if (d.pos >= d.w) d.pos -= d.w;
+}
 // Virtual chunk v (< stream_chunks) -> ray positions [first, end), end - first <= 64.
 __device__ __forceinline__ void stream_chunk(const uint32_t *cnt, uint32_t fixed, uint32_t segcap, uint32_t v, uint32_t &first, uint32_t &end) {
     if (!cnt) {
@@ -535,7 +554,7 @@ __global__ void __launch_bounds__(MI_BLOCK, 6)
 k_extend(DevScene sc, const uint32_t *count_ptr, uint32_t fixed_count, uint32_t segcap,
          const float4 *ray_o, const float4 *ray_d, float4 *hits, int *ovf, unsigned long long *work_stats, int refill_min,
          int leaf_min, ShardGeom g, uint32_t pix0, uint32_t npix, uint32_t *primary_count,
-         const uint32_t *tail_level, int level) {
+         const uint32_t *tail_level, int level, uint32_t deal_rot) {
     __shared__ int lds_stack[MI_LDS_STACK * MI_BLOCK];
     if (!PRIMARY && tail_level && tail_took_over(tail_level, level)) return;
     __shared__ uint4 lds_treelet[MI_TREELET * 4];
@@ -555,7 +574,8 @@ k_extend(DevScene sc, const uint32_t *count_ptr, uint32_t fixed_count, uint32_t 
     const uint32_t n_waves = gridDim.x * (MI_BLOCK / 64);
     const uint32_t wave_id = __builtin_amdgcn_readfirstlane(blockIdx.x * (MI_BLOCK / 64) + (threadIdx.x >> 6));
     const uint32_t n_chunks = stream_chunks(count_ptr, fixed_count);
-    uint32_t chunk = wave_id;           // next virtual chunk of this wave (wave-uniform)
+    ChunkDeal deal = deal_start(wave_id, n_waves, deal_rot);
+    uint32_t chunk = deal_chunk(deal);  // next virtual chunk of this wave (wave-uniform)
     uint32_t rng_next = 0, rng_end = 0; // wave-uniform, ray positions
     bool more = chunk < n_chunks;       // wave-uniform: rays may remain for this wave
     uint32_t n_nodes = 0, n_leaves = 0, ray_steps = 0, max_ray_steps = 0, wave_iters = 0;
@@ -588,7 +608,8 @@ k_extend(DevScene sc, const uint32_t *count_ptr, uint32_t fixed_count, uint32_t 
                 stream_chunk(count_ptr, fixed_count, segcap, chunk, rng_next, rng_end);
                 rng_next = __builtin_amdgcn_readfirstlane(rng_next);
                 rng_end = __builtin_amdgcn_readfirstlane(rng_end);
-                chunk += n_waves;
+                deal_next(deal);
+                chunk = deal_chunk(deal);
                 if (PRIMARY) {
                     chunk_first = rng_next;
                     f3 co = mk3(0, 0, 0), cd = mk3(0, 0, 0);
@@ -978,7 +999,8 @@ k_tail(DevScene sc, ShardGeom g, uint32_t pix0, uint32_t npix, int level0, int d
     const uint32_t n_waves = gridDim.x * (MI_BLOCK / 64);
     const uint32_t wave_id = __builtin_amdgcn_readfirstlane(blockIdx.x * (MI_BLOCK / 64) + (threadIdx.x >> 6));
     const uint32_t n_chunks = stream_chunks(count_ptr, 0u);
-    uint32_t chunk = wave_id;           // static interleaved virtual chunks: wave w takes w, w+W, ... (wave-uniform)
+    ChunkDeal deal = deal_start(wave_id, n_waves, 0u);
+    uint32_t chunk = deal_chunk(deal);  // static deal of the virtual chunks (wave-uniform)
     uint32_t rng_next = 0, rng_end = 0; // wave-uniform, in rays
     uint32_t n_extra = 0;               // wave-uniform
 
@@ -1000,7 +1022,8 @@ k_tail(DevScene sc, ShardGeom g, uint32_t pix0, uint32_t npix, int level0, int d
                 stream_chunk(count_ptr, 0u, in.segcap, chunk, rng_next, rng_end);
                 rng_next = __builtin_amdgcn_readfirstlane(rng_next);
                 rng_end = __builtin_amdgcn_readfirstlane(rng_end);
-                chunk += n_waves;
+                deal_next(deal);
+                chunk = deal_chunk(deal);
             }
             if (rng_next < rng_end) {
                 const uint32_t rank = (uint32_t)__popcll(~act & ((1ull << lane) - 1ull));

@@ -690,6 +690,23 @@ MI_API mi_status mi_scene_upload_build(mi_ctx *c, const mi_scene_soa *s, const f
     return MI_OK;
 }
 
+// Rotation of the level-0 chunk deal (ChunkDeal in mi_kernels.h).  The slots of a batch are sample-major
+// (slot = sample * npix + pixel), so the virtual chunks repeat with period P = npix / 64 per sample; wave
+// w's k-th chunk sits at pixel position (w + k * (W + rot)) mod P and visits P / gcd(W + rot, P) distinct
+// positions.  0 (the plain deal) unless that count is small; then the first rotation near 0.618 W whose
+// count is not.
+static uint32_t deal_rotation(uint32_t n_waves, uint32_t npix, int spp) {
+    if (spp <= 1 || npix % 64u != 0u || n_waves < 8u) return 0u;
+    const uint32_t P = npix / 64u;
+    auto gcd = [](uint32_t a, uint32_t b) { while (b) { uint32_t t = a % b; a = b; b = t; } return a; };
+    auto distinct = [&](uint32_t rot) { return P / gcd((n_waves + rot) % P == 0u ? P : (n_waves + rot) % P, P); };
+    const uint32_t want = std::min<uint32_t>(P, 256u);
+    if (distinct(0u) >= want) return 0u;
+    uint32_t rot = (uint32_t)((unsigned long long)n_waves * 2654435769ull >> 32) | 1u;
+    for (int tries = 0; tries < 64 && rot + 2u < n_waves && distinct(rot) < want; tries++) rot += 2u;
+    return rot < n_waves ? rot : 0u;
+}
+
 static mi_status make_geom(const mi_render_params *p, ShardGeom &g) {
     if (!p) return fail(MI_ERR_INVALID, "params is NULL");
     if (p->width <= 0 || p->height <= 0 || p->samples_per_dim <= 0 || p->samples_per_dim > 1024)
@@ -798,6 +815,7 @@ MI_API mi_status mi_render_device(mi_ctx *c, const mi_render_params *p, void *d_
         const uint32_t pix0 = (uint32_t)(b * npix_b);
         const uint32_t np = (uint32_t)std::min<int64_t>(npix_b, local - (int64_t)pix0);
         const int64_t nslots = (int64_t)np * spp;
+        const uint32_t rot0 = deal_rotation((uint32_t)(c->n_cu * c->extend_wg_primary) * (MI_BLOCK / 64), np, spp);
         HIPCHK(hipMemsetAsync(cnt, 0, kCounterWords * 4, st));
         for (int k = 0; k < levels; k++) {
             const RayStream &sin = rs[k & 1], &sout = rs[(k + 1) & 1];
@@ -811,7 +829,7 @@ MI_API mi_status mi_render_device(mi_ctx *c, const mi_render_params *p, void *d_
 #define MI_EXTEND_ARGS(PRIM)                                                                                                   \
     dim3((PRIM) ? c->n_cu * c->extend_wg_primary : egrid), dim3(MI_BLOCK), 0, st, c->sc, (PRIM) ? (const uint32_t *)nullptr : cnt + k * kLevelWords,                   \
         (PRIM) ? (uint32_t)nslots : 0u, segcap, sin.o, sin.d, c->hits.as<float4>(), c->ovf.as<int>(), ws,                          \
-        (PRIM) ? c->refill_primary : c->refill_min, c->leaf_min, g, pix0, np, cnt, tail_level, k
+        (PRIM) ? c->refill_primary : c->refill_min, c->leaf_min, g, pix0, np, cnt, tail_level, k, (PRIM) ? rot0 : 0u
             if (k == 0) {
                 if (count_work) hipLaunchKernelGGL((k_extend<true, true>), MI_EXTEND_ARGS(true));
                 else hipLaunchKernelGGL((k_extend<false, true>), MI_EXTEND_ARGS(true));
@@ -990,7 +1008,7 @@ static mi_status probe_chunk(mi_ctx *c, int64_t n, int32_t *prim_id_out, float *
     hipLaunchKernelGGL((k_extend<false, false>), dim3(extend_grid(c)), dim3(MI_BLOCK), 0, st, c->sc,
                        (const uint32_t *)nullptr, (uint32_t)n, 0u, c->ray_o[0].as<float4>(), c->ray_d[0].as<float4>(), c->hits.as<float4>(),
                        c->ovf.as<int>(), (unsigned long long *)nullptr, c->refill_min, c->leaf_min, ShardGeom{}, 0u, 1u,
-                       (uint32_t *)nullptr, (const uint32_t *)nullptr, 0);
+                       (uint32_t *)nullptr, (const uint32_t *)nullptr, 0, 0u);
     hipLaunchKernelGGL(k_probe_out, dim3((unsigned)((n + MI_BLOCK - 1) / MI_BLOCK)), dim3(MI_BLOCK), 0, st, c->sc, n, c->ray_o[0].as<float4>(),
                        c->ray_d[0].as<float4>(), c->hits.as<float4>(), c->probe_i.as<int32_t>(), c->probe_t.as<float>(),
                        n_out ? c->probe_n.as<float>() : nullptr);
@@ -1078,7 +1096,7 @@ MI_API mi_status mi_occluded_rays(mi_ctx *c, int64_t total, const float *rays, c
         hipLaunchKernelGGL((k_extend<false, false, true>), dim3(extend_grid(c)), dim3(MI_BLOCK), 0, st, c->sc, (const uint32_t *)nullptr, (uint32_t)n,
                            0u, c->ray_o[0].as<float4>(), c->ray_d[0].as<float4>(), c->hits.as<float4>(), c->ovf.as<int>(),
                            (unsigned long long *)nullptr, c->refill_min, c->leaf_min, ShardGeom{}, 0u, 1u, (uint32_t *)nullptr,
-                           (const uint32_t *)nullptr, 0);
+                           (const uint32_t *)nullptr, 0, 0u);
         hipLaunchKernelGGL(k_probe_occluded, dim3((unsigned)((n + MI_BLOCK - 1) / MI_BLOCK)), dim3(MI_BLOCK), 0, st, n, c->hits.as<float4>(),
                            c->probe_i.as<uint8_t>());
         HIPCHK(hipGetLastError());
