@@ -768,7 +768,10 @@ MI_API mi_status mi_render_device(mi_ctx *c, const mi_render_params *p, void *d_
     const int64_t local = shard_pixels(g);
     const int spp = g.samples * g.samples;
     const int levels = p->depth + 2; // rays per path <= D+2 (CpuTracer.cu:119-131)
-    int64_t want = p->batch_paths > 0 ? p->batch_paths : (int64_t)64 << 20;
+    // default batch: 64 Mi path slots, fewer for deep paths so that the per-batch state (32 B of history per
+    // level, two ray streams, hits, path values: ~128 B + 32 B per level and slot) stays below ~32 GB
+    const int64_t per_slot = 128 + 32 * (int64_t)std::max(1, p->depth + 1);
+    int64_t want = p->batch_paths > 0 ? p->batch_paths : std::min<int64_t>((int64_t)64 << 20, std::max<int64_t>((int64_t)1 << 20, ((int64_t)32 << 30) / per_slot));
     want = std::min<int64_t>(want, (int64_t)1 << 30);
     int64_t npix_b = std::max<int64_t>(64, want / spp / 64 * 64);
     npix_b = std::min(npix_b, std::max<int64_t>(local, 1));
