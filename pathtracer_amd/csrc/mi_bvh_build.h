@@ -42,46 +42,50 @@ k_build_prim_bounds(uint32_t n_tri, uint32_t n_sph, const float *tri_verts, cons
         for (int k = 0; k < 3; k++) { b.lo[k] = c[k] - cr.w; b.hi[k] = c[k] + cr.w; }
     }
     if (i < n) pb[i] = b;
-    // scene box: wave reduction, then one float atomic per wave and component (floats of
-    // either sign order correctly through the int/uint trick below)
+    // scene box [0..5] and box of the centroids [8..13] (the Morton grid spans the latter: a ground plane
+    // of two triangles does not coarsen the grid the mesh is sorted on): wave reduction, then one float
+    // atomic per wave and component (floats of either sign order correctly through the int/uint trick)
     for (int k = 0; k < 3; k++) {
         float lo = b.lo[k], hi = b.hi[k];
+        float clo = i < n ? 0.5f * (b.lo[k] + b.hi[k]) : 3.0e38f, chi = i < n ? clo : -3.0e38f;
         for (int off = 32; off > 0; off >>= 1) {
             lo = fminf(lo, __shfl_xor(lo, off));
             hi = fmaxf(hi, __shfl_xor(hi, off));
+            clo = fminf(clo, __shfl_xor(clo, off));
+            chi = fmaxf(chi, __shfl_xor(chi, off));
         }
         if ((threadIdx.x & 63) == 0) {
             // atomicMin/Max on floats via ordered-int encoding
             if (lo >= 0) atomicMin((int *)&scene_box[k], __float_as_int(lo)); else atomicMax((unsigned int *)&scene_box[k], __float_as_uint(lo));
             if (hi >= 0) atomicMax((int *)&scene_box[3 + k], __float_as_int(hi)); else atomicMin((unsigned int *)&scene_box[3 + k], __float_as_uint(hi));
+            if (clo >= 0) atomicMin((int *)&scene_box[8 + k], __float_as_int(clo)); else atomicMax((unsigned int *)&scene_box[8 + k], __float_as_uint(clo));
+            if (chi >= 0) atomicMax((int *)&scene_box[11 + k], __float_as_int(chi)); else atomicMin((unsigned int *)&scene_box[11 + k], __float_as_uint(chi));
         }
     }
 }
 
-__device__ __forceinline__ uint32_t expand_bits10(uint32_t v) { // 10 bits -> every third bit
-    v = (v * 0x00010001u) & 0xFF0000FFu;
-    v = (v * 0x00000101u) & 0x0F00F00Fu;
-    v = (v * 0x00000011u) & 0xC30C30C3u;
-    v = (v * 0x00000005u) & 0x49249249u;
-    return v;
+__device__ __forceinline__ uint64_t expand_bits12(uint32_t v) { // 12 bits -> every third bit of 36
+    uint64_t r = 0;
+    for (int b = 0; b < 12; b++) r |= (uint64_t)((v >> b) & 1u) << (3 * b);
+    return r;
 }
 
-// key = (30-bit Morton code of the centroid) << 32 | primitive slot: unique, so the
-// common-prefix function is well defined for coincident centroids.
+// key = (36-bit Morton code of the centroid in the box of all centroids) << 26 | primitive slot (< 2^26):
+// unique, so the common-prefix function is well defined for coincident centroids.
 __global__ void __launch_bounds__(MI_BUILD_BLOCK)
 k_build_morton(uint32_t n, const BuildBox *pb, const float *scene_box, uint64_t *keys, uint32_t *vals) {
     const uint32_t i = blockIdx.x * MI_BUILD_BLOCK + threadIdx.x;
     if (i >= n) return;
-    uint32_t code = 0;
+    uint64_t code = 0;
     for (int k = 0; k < 3; k++) {
-        const float lo = scene_box[k], hi = scene_box[3 + k];
+        const float lo = scene_box[8 + k], hi = scene_box[11 + k];
         const float c = 0.5f * (pb[i].lo[k] + pb[i].hi[k]);
         const float ext = hi - lo;
         float u = ext > 0 ? (c - lo) / ext : 0.0f;
-        u = fminf(fmaxf(u * 1024.0f, 0.0f), 1023.0f);
-        code |= expand_bits10((uint32_t)u) << (2 - k);
+        u = fminf(fmaxf(u * 4096.0f, 0.0f), 4095.0f);
+        code |= expand_bits12((uint32_t)u) << (2 - k);
     }
-    keys[i] = ((uint64_t)code << 32) | i;
+    keys[i] = (code << 26) | i;
     vals[i] = i;
 }
 

@@ -531,7 +531,7 @@ MI_API mi_status mi_scene_upload_build(mi_ctx *c, const mi_scene_soa *s, const f
         HIPCHK(verts.ensure(std::max<size_t>((size_t)s->n_tri * 36, 16)));
         if (s->n_tri) HIPCHK(hipMemcpyAsync(verts.p, tri_verts, (size_t)s->n_tri * 36, hipMemcpyHostToDevice, st));
         HIPCHK(pb.ensure((size_t)n * sizeof(BuildBox)));
-        HIPCHK(sbox.ensure(32));
+        HIPCHK(sbox.ensure(64));
         HIPCHK(keys_a.ensure((size_t)n * 8));
         HIPCHK(keys_b.ensure((size_t)n * 8));
         HIPCHK(vals_a.ensure((size_t)n * 4));
@@ -553,8 +553,9 @@ MI_API mi_status mi_scene_upload_build(mi_ctx *c, const mi_scene_soa *s, const f
         mi_status evs = get_events(c, 2); // the context's first two events bracket the build
         if (evs != MI_OK) return evs;
         hipEvent_t e0 = c->ev[0], e1 = c->ev[1];
-        const float init_box[8] = {3.0e38f, 3.0e38f, 3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f, 0, 0};
-        HIPCHK(hipMemcpyAsync(sbox.p, init_box, 32, hipMemcpyHostToDevice, st));
+        const float init_box[16] = {3.0e38f, 3.0e38f, 3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f, 0, 0, // scene box, two counters
+                                    3.0e38f, 3.0e38f, 3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f, 0, 0}; // box of the centroids
+        HIPCHK(hipMemcpyAsync(sbox.p, init_box, 64, hipMemcpyHostToDevice, st));
         HIPCHK(hipStreamSynchronize(st)); // host sources above are stack/borrowed memory
         HIPCHK(hipEventRecord(e0, st));
         const dim3 grid((n + MI_BUILD_BLOCK - 1) / MI_BUILD_BLOCK), block(MI_BUILD_BLOCK);
