@@ -266,7 +266,7 @@ k_build_emit4(int n_nodes, const float4 *nodes2, const uint32_t *flag, const uin
 // the smallest surface area; mutual nearest neighbours merge into a new interior node; the
 // survivors are compacted in order.  A few dozen rounds; tree quality close to a top-down
 // SAH build at a build time close to the LBVH's.
-#define MI_PLOC_RADIUS 16
+#define MI_PLOC_RADIUS 4 // measured with the 36-bit Morton order: 2/4/8/16/32/64 -> C3 7732/7706/7673/7627/7484/7427, C4 6671/6632/6517/6523/6407/6355 Mrays/s (2 loses 3 % on C5)
 
 __global__ void __launch_bounds__(MI_BUILD_BLOCK)
 k_ploc_init(int n, const uint32_t *sorted_slot, const BuildBox *pb, int *cl_ref, BuildBox *cl_box) {
