@@ -701,7 +701,7 @@ static uint32_t deal_rotation(uint32_t n_waves, uint32_t npix, int spp) {
     const uint32_t P = npix / 64u;
     auto gcd = [](uint32_t a, uint32_t b) { while (b) { uint32_t t = a % b; a = b; b = t; } return a; };
     auto distinct = [&](uint32_t rot) { return P / gcd((n_waves + rot) % P == 0u ? P : (n_waves + rot) % P, P); };
-    const uint32_t want = std::min<uint32_t>(P, 256u);
+    const uint32_t want = std::min<uint32_t>(P, 64u); // a wave deals with ~100 chunks per launch: 64 positions average the image well
     if (distinct(0u) >= want) return 0u;
     uint32_t rot = (uint32_t)((unsigned long long)n_waves * 2654435769ull >> 32) | 1u;
     for (int tries = 0; tries < 64 && rot + 2u < n_waves && distinct(rot) < want; tries++) rot += 2u;
