@@ -982,7 +982,7 @@ k_shade(DevScene sc, ShardGeom g, uint32_t pix0, uint32_t npix, int level, int d
 __global__ void __launch_bounds__(MI_BLOCK, 5)
 k_tail(DevScene sc, ShardGeom g, uint32_t pix0, uint32_t npix, int level0, int depth_total, uint64_t seed, RayStream in,
        const uint32_t *count_ptr, uint32_t threshold, uint32_t *tail_level, float4 *hist, size_t cap, float4 *path_out, int *ovf,
-       unsigned long long *extra_rays, int leaf_min, int shade_min) {
+       unsigned long long *extra_rays, int shade_min) {
     __shared__ int lds_stack[MI_LDS_STACK * MI_BLOCK];
     const uint32_t n = stream_total(count_ptr);
     const uint32_t tl = *tail_level;

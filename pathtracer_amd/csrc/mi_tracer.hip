@@ -828,7 +828,7 @@ MI_API mi_status mi_render_device(mi_ctx *c, const mi_render_params *p, void *d_
             if (k >= 1 && c->tail_threshold > 0 && !count_work)
                 hipLaunchKernelGGL(k_tail, dim3(c->n_cu * c->tail_wg_per_cu), dim3(MI_BLOCK), 0, st, c->sc, g, pix0, np, k, p->depth, p->seed, sin, cnt + k * kLevelWords,
                                    (uint32_t)c->tail_threshold, tail_level, c->hist.as<float4>(), cap, c->path_out.as<float4>(), c->ovf.as<int>(),
-                                   c->totals.as<unsigned long long>() + 7, c->leaf_min, c->shade_min);
+                                   c->totals.as<unsigned long long>() + 7, c->shade_min);
             if (per_launch) HIPCHK(hipEventRecord(c->ev[evi++], st));
 #define MI_EXTEND_ARGS(PRIM)                                                                                                   \
     dim3((PRIM) ? c->n_cu * c->extend_wg_primary : egrid), dim3(MI_BLOCK), 0, st, c->sc, (PRIM) ? (const uint32_t *)nullptr : cnt + k * kLevelWords,                   \
