@@ -982,7 +982,7 @@ k_shade(DevScene sc, ShardGeom g, uint32_t pix0, uint32_t npix, int level, int d
 __global__ void __launch_bounds__(MI_BLOCK, 5)
 k_tail(DevScene sc, ShardGeom g, uint32_t pix0, uint32_t npix, int level0, int depth_total, uint64_t seed, RayStream in,
        const uint32_t *count_ptr, uint32_t threshold, uint32_t *tail_level, float4 *hist, size_t cap, float4 *path_out, int *ovf,
-       unsigned long long *extra_rays, int shade_min) {
+       unsigned long long *extra_rays, int shade_min, int refill_min) {
     __shared__ int lds_stack[MI_LDS_STACK * MI_BLOCK];
     const uint32_t n = stream_total(count_ptr);
     const uint32_t tl = *tail_level;
@@ -1017,7 +1017,7 @@ k_tail(DevScene sc, ShardGeom g, uint32_t pix0, uint32_t npix, int level0, int d
     bool more = true; // wave-uniform
     do {              // single back edge, no `continue` (see k_extend)
         const int n_idle = 64 - __popcll(act);
-        if (more && (n_idle >= 16 || act == 0ull)) {
+        if (more && (n_idle >= refill_min || act == 0ull)) {
             if (rng_next >= rng_end && chunk < n_chunks) {
                 stream_chunk(count_ptr, 0u, in.segcap, chunk, rng_next, rng_end);
                 rng_next = __builtin_amdgcn_readfirstlane(rng_next);

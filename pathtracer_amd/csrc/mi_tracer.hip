@@ -75,6 +75,7 @@ struct mi_ctx {
     int refill_min = 20;        // MI_TRACER_REFILL: idle lanes that trigger a refill
     int refill_primary = 12;    // MI_TRACER_REFILL_PRIMARY: the same at level 0, where a refill only reads parked camera rays
     int leaf_min = 16;          // MI_TRACER_LEAF_MIN: lanes with a pending leaf that trigger a leaf phase
+    int tail_refill = 16;       // MI_TRACER_TAIL_REFILL: idle lanes that trigger a refill in k_tail
     int shade_min = 24;         // MI_TRACER_SHADE_MIN: lanes waiting to be shaded that trigger a shade phase of k_tail
     int shade_wg_per_cu = 8;    // MI_TRACER_SHADE_WG_PER_CU: workgroups of k_shade per CU (grid-stride loop)
     int tail_wg_per_cu = 4;     // workgroups of k_tail resident per CU (occupancy query at context creation)
@@ -120,6 +121,7 @@ MI_API mi_status mi_ctx_create(int device_id, mi_ctx **out) {
     c->refill_primary = env_int("MI_TRACER_REFILL_PRIMARY", 1, 64, c->refill_primary);
     c->leaf_min = env_int("MI_TRACER_LEAF_MIN", 1, 64, c->leaf_min);
     c->shade_min = env_int("MI_TRACER_SHADE_MIN", 1, 64, c->shade_min);
+    c->tail_refill = env_int("MI_TRACER_TAIL_REFILL", 1, 64, c->tail_refill);
     c->tail_threshold = env_int("MI_TRACER_TAIL", 0, 1 << 30, c->tail_threshold);
     // k_tail is persistent and deals its work statically over the grid: launch exactly as many
     // workgroups as are resident at once (a second round would start after the first has finished)
@@ -828,7 +830,7 @@ MI_API mi_status mi_render_device(mi_ctx *c, const mi_render_params *p, void *d_
             if (k >= 1 && c->tail_threshold > 0 && !count_work)
                 hipLaunchKernelGGL(k_tail, dim3(c->n_cu * c->tail_wg_per_cu), dim3(MI_BLOCK), 0, st, c->sc, g, pix0, np, k, p->depth, p->seed, sin, cnt + k * kLevelWords,
                                    (uint32_t)c->tail_threshold, tail_level, c->hist.as<float4>(), cap, c->path_out.as<float4>(), c->ovf.as<int>(),
-                                   c->totals.as<unsigned long long>() + 7, c->shade_min);
+                                   c->totals.as<unsigned long long>() + 7, c->shade_min, c->tail_refill);
             if (per_launch) HIPCHK(hipEventRecord(c->ev[evi++], st));
 #define MI_EXTEND_ARGS(PRIM)                                                                                                   \
     dim3((PRIM) ? c->n_cu * c->extend_wg_primary : egrid), dim3(MI_BLOCK), 0, st, c->sc, (PRIM) ? (const uint32_t *)nullptr : cnt + k * kLevelWords,                   \
