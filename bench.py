@@ -213,7 +213,15 @@ def main():
                                  "kernel is VALU-issue/latency bound, not HBM bound (DESIGN.md section 3)"},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(scene, w, h, samples, depth, args.cpu_seconds)
+            out["cpu_baseline"], band = cpu_baseline(scene, w, h, samples, depth, args.cpu_seconds)
+            # second half of the metric ("RMSE vs CpuTracer"): the rows the oracle has just rendered against the
+            # same rows of a GPU frame (raycheck's RMS over uint8 RGB, float subtraction); outside the timed region
+            y0, y1, omean, orgb = band
+            gmean, grgb, _ = ctx.render(P.Context.params(w, h, samples, depth, seed=0))
+            d = grgb[y0:y1].astype(np.float64) - orgb[y0:y1].astype(np.float64)
+            out["parity"] = {"rmse_rgb8_vs_oracle": float(np.sqrt((d * d).mean())) if d.size else 0.0,
+                             "radiance_bit_identical": bool(np.array_equal(gmean[y0:y1].view(np.uint32), omean[y0:y1].view(np.uint32))),
+                             "rows": [int(y0), int(y1)], "oracle": "CPU restatement of CpuTracer (parity unpinned, DESIGN.md section 5)"}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
@@ -258,10 +266,11 @@ def cpu_baseline(scene, w, h, samples, depth, budget_s):
     per_row = max(c.ms / rows, 1e-3)
     rows = int(max(2, min(h, budget_s * 1e3 / per_row)))
     y0 = max(0, mid - rows // 2)
-    _, _, c = O.render(scene, p, threads=cores, rows=(y0, min(h, y0 + rows)))
+    y1 = min(h, y0 + rows)
+    omean, orgb, c = O.render(scene, p, threads=cores, rows=(y0, y1))
     return {"value": c.rays / (c.ms * 1e-3) / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
             "sample": f"rows [{y0},{min(h, y0 + rows)}) of the same {w}x{h} workload, {c.rays} rays in {c.ms / 1e3:.1f} s",
-            "nodes_per_ray": c.node_visits / max(1, c.rays), "prim_tests_per_ray": c.leaf_tests / max(1, c.rays)}
+            "nodes_per_ray": c.node_visits / max(1, c.rays), "prim_tests_per_ray": c.leaf_tests / max(1, c.rays)}, (y0, y1, omean, orgb)
 
 
 if __name__ == "__main__":
