@@ -222,6 +222,12 @@ def main():
             out["parity"] = {"rmse_rgb8_vs_oracle": float(np.sqrt((d * d).mean())) if d.size else 0.0,
                              "radiance_bit_identical": bool(np.array_equal(gmean[y0:y1].view(np.uint32), omean[y0:y1].view(np.uint32))),
                              "rows": [int(y0), int(y1)], "oracle": "CPU restatement of CpuTracer (parity unpinned, DESIGN.md section 5)"}
+            from oracle import oracle_py as O
+            pw, ph = scene.image_size(max(64, width // 4))   # primary hits of a quarter-size frame, 1 sample per pixel
+            gid, gt, _ = ctx.trace_primary(pw, ph, 1)
+            oid, ot, _, _ = O.trace_primary(scene, pw, ph, 1, O.BVH_CANONICAL)
+            out["parity"].update({"primary_hit_id_agreement": float((gid == oid).mean()), "primary_hits": int((oid >= 0).sum()),
+                                  "hit_t_bit_identical": bool(np.array_equal(gt.view(np.uint32), ot.view(np.uint32)))})
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
