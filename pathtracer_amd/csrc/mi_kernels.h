@@ -803,11 +803,18 @@ __device__ __forceinline__ float4 cubemap_color(const int32_t *cube, f3 raydir) 
 // The reference evaluates radiance by recursion: value_k = ke_k*32 + w_k (.) value_{k+1}
 // (CpuTracer.cu:152,166,174,185).  To round exactly like it, every level stores
 // (e_k, w_k) and the terminating thread folds them from the deepest level back.
-// hist[(level*cap + slot)*2 + {0,1}] = (e, w): one 32-B record per path and level.
-__device__ __forceinline__ float4 fold_history(const float4 *hist, size_t cap, uint32_t slot, int levels, float4 val) {
+// History of a path: w_k at hist[k*cap + slot], e_k at hist[e_off + k*cap + slot] (16 B each).  Most
+// bounces are off surfaces that emit nothing: e_k is then +0 in all four lanes, is neither written nor
+// read, and bit k of the path's `emask` (which travels with the ray, in the unused w lane of its
+// direction record) stays clear; the fold still ADDS that zero, so the arithmetic is the reference's.
+// Levels >= 31 have no mask bit: their e is always stored.  (One 32-B (e, w) record per level at first:
+// the fold at the end of a Cornell-box path read seven of them, 64 B fetched for each.)
+__device__ __forceinline__ float4 fold_history(const float4 *hist, size_t cap, size_t e_off, uint32_t slot, int levels, uint32_t emask, float4 val) {
     for (int j = levels - 1; j >= 0; j--) {
-        const float4 *rec = hist + ((size_t)j * cap + slot) * 2;
-        float4 e = rec[0], w = rec[1];
+        const size_t at = (size_t)j * cap + slot;
+        const float4 w = hist[at];
+        float4 e = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (j >= 31 || ((emask >> j) & 1u)) e = hist[e_off + at];
         val = add4(e, mul4(w, val));
     }
     return val;
@@ -829,10 +836,10 @@ __device__ __forceinline__ uint64_t path_id(const ShardGeom &g, int px, int py, 
 // Tn is returned with true.
 __device__ __forceinline__ bool shade_path(const DevScene &sc, uint64_t seed, uint64_t path, int level, int depth_left, uint32_t slot,
                                            f3 o, f3 d, float4 T, float t, int pslot, float hu, float hv, float4 *hist,
-                                           size_t cap, float4 *path_out, f3 &no, f3 &nd, float4 &Tn) {
+                                           size_t cap, size_t e_off, uint32_t &emask, float4 *path_out, f3 &no, f3 &nd, float4 &Tn) {
     if (pslot < 0) { // CpuTracer.cu:124-125: miss -> cubemap colour, or (1,1,1,1) without a cubemap
         const float4 bg = sc.cube ? cubemap_color(sc.cube, d) : make_float4(1.0f, 1.0f, 1.0f, 1.0f);
-        path_out[slot] = clamp01_4(fold_history(hist, cap, slot, level, bg));
+        path_out[slot] = clamp01_4(fold_history(hist, cap, e_off, slot, level, emask, bg));
         return false;
     }
     f3 N;
@@ -840,7 +847,7 @@ __device__ __forceinline__ bool shade_path(const DevScene &sc, uint64_t seed, ui
     hit_surface(sc, pslot, t, hu, hv, o, d, N, m);
     float4 e = mul4(m.ke, 32.0f); // CpuTracer.cu:131,185
     if (depth_left < 0) {         // CpuTracer.cu:130-131
-        path_out[slot] = clamp01_4(fold_history(hist, cap, slot, level, e));
+        path_out[slot] = clamp01_4(fold_history(hist, cap, e_off, slot, level, emask, e));
         return false;
     }
     f3 hitInner = o + (t + MI_EPS) * d; // :127
@@ -877,12 +884,15 @@ __device__ __forceinline__ bool shade_path(const DevScene &sc, uint64_t seed, ui
         no = hitOuter; w = m.kd;
     }
     Tn = mul4(w, T); // `w * thresh`, :152,166,174
-    float4 *rec = hist + ((size_t)level * cap + slot) * 2;
-    rec[0] = e;
-    rec[1] = w;
+    const size_t at = (size_t)level * cap + slot;
+    hist[at] = w;
+    if (level >= 31 || ((__float_as_uint(e.x) | __float_as_uint(e.y) | __float_as_uint(e.z) | __float_as_uint(e.w)) != 0u)) {
+        hist[e_off + at] = e;
+        if (level < 31) emask |= 1u << level;
+    }
     // entry test of the next level, CpuTracer.cu:121-122
     if ((double)length2_4(Tn) < 3.0 * 12.0 / 255.0 / 255.0) {
-        path_out[slot] = clamp01_4(fold_history(hist, cap, slot, level + 1, make_float4(0.0f, 0.0f, 0.0f, 0.0f)));
+        path_out[slot] = clamp01_4(fold_history(hist, cap, e_off, slot, level + 1, emask, make_float4(0.0f, 0.0f, 0.0f, 0.0f)));
         return false;
     }
     return true;
@@ -896,7 +906,7 @@ __device__ __forceinline__ bool shade_path(const DevScene &sc, uint64_t seed, ui
 template <bool PRIMARY>
 __global__ void __launch_bounds__(MI_BLOCK)
 k_shade(DevScene sc, ShardGeom g, uint32_t pix0, uint32_t npix, int level, int depth_left, uint64_t seed, RayStream in,
-        const uint32_t *count_ptr, const float4 *hits, float4 *hist, size_t cap, float4 *path_out, RayStream out,
+        const uint32_t *count_ptr, const float4 *hits, float4 *hist, size_t cap, size_t e_off, float4 *path_out, RayStream out,
         uint32_t *next_count, uint32_t n_fixed, const uint32_t *tail_level) {
     if (!PRIMARY && tail_took_over(tail_level, level)) return;
     // i runs over the virtual positions (64 per virtual chunk) of the input stream
@@ -956,15 +966,16 @@ k_shade(DevScene sc, ShardGeom g, uint32_t pix0, uint32_t npix, int level, int d
         }
         f3 no = mk3(0, 0, 0), nd = mk3(0, 0, 0);
         float4 Tn = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        uint32_t emask = PRIMARY ? 0u : __float_as_uint(cur.d4.w); // which earlier levels stored an emission term
         if (live) {
             const float4 h4 = cur.h4;
             alive = shade_path(sc, seed, path_id(g, px, py, samp), level, depth_left, slot, o, d, T, h4.x, __float_as_int(h4.y), h4.z, h4.w,
-                               hist, cap, path_out, no, nd, Tn);
+                               hist, cap, e_off, emask, path_out, no, nd, Tn);
         }
         const uint32_t pos = out_base + queue_reserve(alive, my_count);
         if (alive) {
             out.o[pos] = make_float4(no.x, no.y, no.z, __int_as_float((int)slot));
-            out.d[pos] = make_float4(nd.x, nd.y, nd.z, 0.0f);
+            out.d[pos] = make_float4(nd.x, nd.y, nd.z, __uint_as_float(emask));
             out.thr[pos] = Tn;
         }
     }
@@ -981,7 +992,7 @@ k_shade(DevScene sc, ShardGeom g, uint32_t pix0, uint32_t npix, int level, int d
 // immediately.  Rays traced beyond the first level are added to *extra_rays.
 __global__ void __launch_bounds__(MI_BLOCK, 5)
 k_tail(DevScene sc, ShardGeom g, uint32_t pix0, uint32_t npix, int level0, int depth_total, uint64_t seed, RayStream in,
-       const uint32_t *count_ptr, uint32_t threshold, uint32_t *tail_level, float4 *hist, size_t cap, float4 *path_out, int *ovf,
+       const uint32_t *count_ptr, uint32_t threshold, uint32_t *tail_level, float4 *hist, size_t cap, size_t e_off, float4 *path_out, int *ovf,
        unsigned long long *extra_rays, int shade_min, int refill_min) {
     __shared__ int lds_stack[MI_LDS_STACK * MI_BLOCK];
     const uint32_t n = stream_total(count_ptr);
@@ -1005,7 +1016,7 @@ k_tail(DevScene sc, ShardGeom g, uint32_t pix0, uint32_t npix, int level0, int d
     uint32_t n_extra = 0;               // wave-uniform
 
     bool active = false;
-    uint32_t slot = 0;
+    uint32_t slot = 0, emask = 0;
     int level = level0;
     float4 T = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     Lane L;
@@ -1033,7 +1044,9 @@ k_tail(DevScene sc, ShardGeom g, uint32_t pix0, uint32_t npix, int level0, int d
                     slot = (uint32_t)__float_as_int(o4.w);
                     T = in.thr[rng_next + rank];
                     level = level0;
-                    lane_start(sc, L, xyz(o4), xyz(in.d[rng_next + rank]));
+                    const float4 d4 = in.d[rng_next + rank];
+                    emask = __float_as_uint(d4.w);
+                    lane_start(sc, L, xyz(o4), xyz(d4));
                     active = true;
                 }
                 rng_next += (uint32_t)n_idle < avail ? (uint32_t)n_idle : avail;
@@ -1054,7 +1067,7 @@ k_tail(DevScene sc, ShardGeom g, uint32_t pix0, uint32_t npix, int level0, int d
                 f3 no, nd;
                 float4 Tn;
                 cont = shade_path(sc, seed, path_id(g, px, py, samp), level, depth_total - level, slot, L.o, L.d, T, L.h.t, L.h.slot, L.h.u,
-                                  L.h.v, hist, cap, path_out, no, nd, Tn);
+                                  L.h.v, hist, cap, e_off, emask, path_out, no, nd, Tn);
                 if (cont) {
                     T = Tn;
                     level++;

@@ -829,7 +829,7 @@ MI_API mi_status mi_render_device(mi_ctx *c, const mi_render_params *p, void *d_
             if (per_launch) HIPCHK(hipEventRecord(c->ev[evi++], st)); // 4 events per level: tail | extend | shade
             if (k >= 1 && c->tail_threshold > 0 && !count_work)
                 hipLaunchKernelGGL(k_tail, dim3(c->n_cu * c->tail_wg_per_cu), dim3(MI_BLOCK), 0, st, c->sc, g, pix0, np, k, p->depth, p->seed, sin, cnt + k * kLevelWords,
-                                   (uint32_t)c->tail_threshold, tail_level, c->hist.as<float4>(), cap, c->path_out.as<float4>(), c->ovf.as<int>(),
+                                   (uint32_t)c->tail_threshold, tail_level, c->hist.as<float4>(), cap, (size_t)hist_levels * cap, c->path_out.as<float4>(), c->ovf.as<int>(),
                                    c->totals.as<unsigned long long>() + 7, c->shade_min, c->tail_refill);
             if (per_launch) HIPCHK(hipEventRecord(c->ev[evi++], st));
 #define MI_EXTEND_ARGS(PRIM)                                                                                                   \
@@ -847,7 +847,7 @@ MI_API mi_status mi_render_device(mi_ctx *c, const mi_render_params *p, void *d_
             if (per_launch) HIPCHK(hipEventRecord(c->ev[evi++], st));
 #define MI_SHADE_ARGS                                                                                                          \
     dim3(sgrid), dim3(MI_BLOCK), 0, st, c->sc, g, pix0, np, k, p->depth - k, p->seed, sin, cnt + k * kLevelWords, c->hits.as<float4>(),         \
-        c->hist.as<float4>(), cap, c->path_out.as<float4>(), sout, cnt + (k + 1) * kLevelWords, (uint32_t)nslots, tail_level
+        c->hist.as<float4>(), cap, (size_t)hist_levels * cap, c->path_out.as<float4>(), sout, cnt + (k + 1) * kLevelWords, (uint32_t)nslots, tail_level
             if (k == 0) hipLaunchKernelGGL(k_shade<true>, MI_SHADE_ARGS);
             else hipLaunchKernelGGL(k_shade<false>, MI_SHADE_ARGS);
 #undef MI_SHADE_ARGS

@@ -286,3 +286,24 @@ def test_cli_renders_a_png(tmp_path, scenes_small):
     r = subprocess.run([exe, "-B", "-r", "2", "-w", "64", "-s", "2", "-S", "3", str(ray), str(out2)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert np.array_equal(np.array(Image.open(out2)), img)
+
+
+def test_paths_deeper_than_the_emission_mask(ctx):
+    """The per-path emission mask has 31 bits (fold_history in mi_kernels.h); deeper levels always store their
+    emission term.  A mirror box with a glowing sphere keeps paths alive for dozens of levels."""
+    mat = "material = { diffuse = (0.99,0.99,0.99); reflective = (0.9,0.9,0.9); }"   # bounce weight = kd (CpuTracer.cu:174)
+    walls = ""
+    for sx, sy, sz, tx, ty, tz in ((6, 6, 0.1, 0, 0, -3), (6, 6, 0.1, 0, 0, 8), (0.1, 6, 12, -3, 0, 2), (0.1, 6, 12, 3, 0, 2), (6, 0.1, 12, 0, -3, 2), (6, 0.1, 12, 0, 3, 2)):
+        walls += "translate(%g,%g,%g, scale(%g,%g,%g, box { %s } ))\n" % (tx, ty, tz, sx, sy, sz, mat)
+    text = (H + "camera { position = (0,0,5); viewdir = (0.1,0.05,-1); updir = (0,1,0); fov = 70; aspectratio = 1; }\n" + walls +
+            "translate(0.5,-0.4,0, scale(0.6, sphere { material = { diffuse = (0.95,0.95,0.95); emissive = (0.004,0.003,0.002); reflective = (0.5,0.5,0.5); } }))\n")
+    sc = P.Scene.from_text(text)
+    ctx.upload(sc)
+    p = P.Context.params(40, 40, 2, 45, seed=21)
+    mean, rgb, st = ctx.render(p)
+    omean, orgb, cnt = O.render(sc, p)
+    assert cnt.rays > 40 * 40 * 4 * 33, "paths do not reach the levels beyond the mask"
+    assert st.rays_cast == cnt.rays and same(mean, omean) and np.array_equal(rgb, orgb)
+    pt = P.Context.params(40, 40, 2, 45, seed=21, batch_paths=1500)   # several batches
+    mean2, rgb2, st2 = ctx.render(pt)
+    assert same(mean2, omean) and st2.rays_cast == cnt.rays
