@@ -38,7 +38,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="C3-blob82k-1080p-16spp", choices=sorted(WORKLOADS))
     ap.add_argument("--bvh", default="host", choices=["host", "device"],
-                    help="host: binned-SAH tree built by libpt_host (default); device: LBVH built by mi_scene_upload_build")
+                    help="host: binned-SAH tree built by libpt_host (default); device: built by mi_scene_upload_build (PLOC; MI_TRACER_BUILDER=lbvh for the Karras LBVH)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the N>1 path with several ranks on ONE GPU (tiles staged through the host); never a result")
     ap.add_argument("--check", action="store_true", help="N>1: rank 0 also renders the whole frame alone and compares the assembled frame byte for byte")
@@ -83,7 +83,12 @@ def main():
     rgba8 = torch.zeros(stride * 4, dtype=torch.uint8, device=dev)
     gathered = torch.zeros(world * stride * 4, dtype=torch.uint8, device=dev) if (world > 1 and rank == 0) else None
     frame = torch.zeros(w * h * 3, dtype=torch.uint8, device=dev) if (world > 1 and rank == 0) else None  # assembled frame stays in HBM, like N=1
-    stream = torch.cuda.current_stream().cuda_stream
+    # One explicit (non-default) torch stream carries the renders, the collective's stream dependencies and the
+    # assembly: torch's default stream has handle 0, which mi_render_device would read as "the context's own
+    # stream", ordered with neither torch's current stream nor RCCL's.
+    tstream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(tstream)
+    stream = tstream.cuda_stream
 
     # Exchange step: RGBA8 tiles of every rank -> rank 0.  dist.gather (grouped send/recv in RCCL) moves
     # only what rank 0 needs; should the backend refuse it, all ranks fall back together to an all-gather.
@@ -117,8 +122,10 @@ def main():
                 dist.gather(rgba8, list(gathered.view(world, -1).unbind(0)) if rank == 0 else None, dst=0)
             else:
                 dist.all_gather_into_tensor(gathered, rgba8)
+            # every rank: the gather's send still reads rgba8 on RCCL's stream; work.wait() inside dist.gather only
+            # made the current stream wait for it, so block the host here before the next render overwrites rgba8
+            torch.cuda.current_stream().synchronize()
             if rank == 0:
-                torch.cuda.current_stream().synchronize()
                 ctx.assemble_rgb8_device(params, gathered.data_ptr(), stride, frame.data_ptr(), stream)
                 img = frame
         return st, img

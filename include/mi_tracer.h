@@ -209,8 +209,13 @@ mi_status mi_render(mi_ctx *ctx, const mi_render_params *params,
  *   d_rgba_mean : device float4[mi_shard_pixels()] or NULL
  *   d_rgba8     : device uint8[4*mi_shard_pixels()] (r,g,b,255) or NULL
  * Pixels of edge tiles that fall outside the image are written as zeros.
- * `stream` is a hipStream_t (NULL = default stream).  The call enqueues work and
- * synchronises the stream before returning. */
+ * `stream` is a hipStream_t; NULL selects the context's OWN stream (created with
+ * hipStreamNonBlocking: it is ordered with no other stream, not with the legacy default
+ * stream either).  The call enqueues its work on that stream and synchronises it before
+ * returning, so the outputs are complete on return.  The context's buffers and the caller's
+ * outputs are ordered only with the stream passed in: work of the caller that still reads
+ * d_rgba8 / d_rgba_mean on another stream (e.g. a collective) must have finished, or be
+ * ordered before this stream, when the next call is made. */
 mi_status mi_render_device(mi_ctx *ctx, const mi_render_params *params,
                            void *d_rgba_mean, void *d_rgba8, void *stream,
                            mi_stats *stats);

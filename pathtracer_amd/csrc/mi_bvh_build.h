@@ -5,7 +5,7 @@
 // names BVH quality as "the significant factor".  This builder is not a restatement of
 // that algorithm ("not to be replicated") — the closest hit does not depend on
 // the tree (canonical tie rule + padded boxes), so any valid tree renders
-// the same image bit for bit.  30-bit Morton codes of the primitive centroids, one radix
+// the same image bit for bit.  36-bit Morton codes of the primitive centroids (on the box of the centroids), one radix
 // sort (hipCUB), primitive records gathered into that order, then either PLOC (default:
 // rounds of nearest-neighbour search in a window, mutual pairs merge) or an LBVH (Karras
 // 2012: every interior node found independently from the longest common prefix of
@@ -55,7 +55,10 @@ k_build_prim_bounds(uint32_t n_tri, uint32_t n_sph, const float *tri_verts, cons
             chi = fmaxf(chi, __shfl_xor(chi, off));
         }
         if ((threadIdx.x & 63) == 0) {
-            // atomicMin/Max on floats via ordered-int encoding
+            // atomicMin/Max on floats via ordered-int encoding.  -0.0 is canonicalised to +0.0 first (x + 0.0f):
+            // its bit pattern is INT_MIN, which as an int would replace a stored negative lower bound and, on
+            // the upper side, could never win.
+            lo += 0.0f; hi += 0.0f; clo += 0.0f; chi += 0.0f;
             if (lo >= 0) atomicMin((int *)&scene_box[k], __float_as_int(lo)); else atomicMax((unsigned int *)&scene_box[k], __float_as_uint(lo));
             if (hi >= 0) atomicMax((int *)&scene_box[3 + k], __float_as_int(hi)); else atomicMin((unsigned int *)&scene_box[3 + k], __float_as_uint(hi));
             if (clo >= 0) atomicMin((int *)&scene_box[8 + k], __float_as_int(clo)); else atomicMax((unsigned int *)&scene_box[8 + k], __float_as_uint(clo));

@@ -92,6 +92,10 @@ static const int kLevelWords = MI_SUB * MI_CNT_STRIDE; // counter j of a level a
 static const int kCounterWords = (kMaxLevels + 1) * kLevelWords + MI_CNT_STRIDE;
 
 static int extend_grid(const mi_ctx *c) { return c->n_cu * c->extend_wg_per_cu; }
+// Workgroups of the largest persistent launch (k_extend, its level-0 variant, k_tail): every one of their
+// threads owns a column of the global overflow stack, indexed by blockIdx.x * MI_BLOCK + threadIdx.x.
+static int stack_grid(const mi_ctx *c) { return c->n_cu * std::max(c->extend_wg_per_cu, std::max(c->extend_wg_primary, c->tail_wg_per_cu)); }
+static size_t stack_bytes(const mi_ctx *c) { return (size_t)(MI_MAX_STACK - MI_LDS_STACK) * stack_grid(c) * MI_BLOCK * 4; }
 
 MI_API int mi_abi_version(void) { return 9; }
 MI_API const char *mi_last_error(void) { return g_err.c_str(); }
@@ -123,12 +127,6 @@ MI_API mi_status mi_ctx_create(int device_id, mi_ctx **out) {
     c->shade_min = env_int("MI_TRACER_SHADE_MIN", 1, 64, c->shade_min);
     c->tail_refill = env_int("MI_TRACER_TAIL_REFILL", 1, 64, c->tail_refill);
     c->tail_threshold = env_int("MI_TRACER_TAIL", 0, 1 << 30, c->tail_threshold);
-    // k_tail is persistent and deals its work statically over the grid: launch exactly as many
-    // workgroups as are resident at once (a second round would start after the first has finished)
-    int occ = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_tail, MI_BLOCK, 0) == hipSuccess && occ > 0)
-        c->tail_wg_per_cu = std::min(occ, c->extend_wg_per_cu);
-    c->tail_wg_per_cu = env_int("MI_TRACER_TAIL_WG_PER_CU", 1, 16, c->tail_wg_per_cu);
     // k_shade walks its stream with a grid-stride loop: a grid that is a multiple of what is resident
     // at once keeps the last round full (8 per CU against 5 resident measured 9 % slower than 5 or 10)
     int occ_s = 0;
@@ -143,6 +141,14 @@ MI_API mi_status mi_ctx_create(int device_id, mi_ctx **out) {
     c->extend_wg_primary = c->extend_wg_per_cu;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_e, k_extend<false, true, false>, MI_BLOCK, 0) == hipSuccess && occ_e > 0)
         c->extend_wg_primary = std::min(c->extend_wg_primary, occ_e);
+    // k_tail is persistent and deals its work statically over the grid: launch exactly as many
+    // workgroups as are resident at once (a second round would start after the first has finished).
+    // Computed after extend_wg_per_cu is final; the overflow stacks are sized for the largest of the
+    // persistent grids (stack_grid), so an override above k_extend's count stays in bounds.
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_tail, MI_BLOCK, 0) == hipSuccess && occ > 0)
+        c->tail_wg_per_cu = std::min(occ, c->extend_wg_per_cu);
+    c->tail_wg_per_cu = env_int("MI_TRACER_TAIL_WG_PER_CU", 1, 16, c->tail_wg_per_cu);
     hipError_t es = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (es != hipSuccess) { delete c; return fail(MI_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(es)); }
     es = hipHostMalloc((void **)&c->h_totals, kTotals * sizeof(uint64_t), hipHostMallocDefault);
@@ -189,10 +195,12 @@ static mi_status validate_prims(const mi_scene_soa *s) {
 static mi_status validate_scene(const mi_scene_soa *s) {
     const uint64_t n_prim = (uint64_t)s->n_tri + s->n_sph;
     mi_status ps = validate_prims(s);
-    if (ps != MI_OK || n_prim == 0) return ps;
+    if (ps != MI_OK) return ps;
+    if (n_prim == 0) return s->n_nodes == 0 ? MI_OK : fail(MI_ERR_INVALID, "scene: no primitives, n_nodes must be 0");
     if (s->n_nodes >= (1u << 26)) return fail(MI_ERR_INVALID, "scene: more than 2^26 nodes");
     if (n_prim == 1) {
         if (s->root_ref != ~0) return fail(MI_ERR_INVALID, "scene: one primitive needs root_ref == ~0");
+        if (s->n_nodes != 0) return fail(MI_ERR_INVALID, "scene: one primitive has no interior node, n_nodes must be 0");
         return MI_OK;
     }
     if (s->n_nodes != n_prim - 1 || !s->nodes) return fail(MI_ERR_INVALID, "scene: %u nodes for %llu primitives (want n-1)", s->n_nodes, (unsigned long long)n_prim);
@@ -426,7 +434,7 @@ MI_API mi_status mi_scene_upload(mi_ctx *c, const mi_scene_soa *s) {
 // box, + 1 for the root: the SAH cost with unit node and leaf costs.
 static mi_status resident_sah_cost(mi_ctx *c, double *out) {
     *out = 0.0;
-    if (c->n_nodes == 0) return MI_OK;
+    if (c->n_nodes == 0 || c->root_ref2 < 0 || (uint32_t)c->root_ref2 >= c->n_nodes) return MI_OK; // no interior node
     DevBuf acc;
     HIPCHK(acc.ensure(8));
     HIPCHK(hipMemsetAsync(acc.p, 0, 8, c->stream));
@@ -802,7 +810,7 @@ MI_API mi_status mi_render_device(mi_ctx *c, const mi_render_params *p, void *d_
     HIPCHK(c->hist.ensure(cap * 32 * hist_levels));
     HIPCHK(c->counters.ensure(kCounterWords * 4));
     const int egrid = extend_grid(c);
-    HIPCHK(c->ovf.ensure((size_t)(MI_MAX_STACK - MI_LDS_STACK) * egrid * MI_BLOCK * 4));
+    HIPCHK(c->ovf.ensure(stack_bytes(c)));
     HIPCHK(c->totals.ensure(kTotals * 8));
     const int64_t n_batches = local > 0 ? (local + npix_b - 1) / npix_b : 0;
     const size_t n_ev = 2 + (size_t)n_batches * levels * 4;
@@ -1033,7 +1041,7 @@ static mi_status probe_alloc(mi_ctx *c, size_t chunk) {
     HIPCHK(c->probe_i.ensure(chunk * 4));
     HIPCHK(c->probe_t.ensure(chunk * 4));
     HIPCHK(c->probe_n.ensure(chunk * 12));
-    HIPCHK(c->ovf.ensure((size_t)(MI_MAX_STACK - MI_LDS_STACK) * extend_grid(c) * MI_BLOCK * 4));
+    HIPCHK(c->ovf.ensure(stack_bytes(c)));
     return MI_OK;
 }
 
