@@ -220,6 +220,32 @@ mi_status mi_render_device(mi_ctx *ctx, const mi_render_params *params,
                            void *d_rgba_mean, void *d_rgba8, void *stream,
                            mi_stats *stats);
 
+/* mi_render_device for callers that CANNOT ALLOCATE: code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc.  NO counterpart in the reference (its GpuTracer::traceImage
+ * allocates on every call, GpuTracer.cu:165-176).  Same arguments, same outputs, bit for bit; the call
+ * makes no hipMalloc / hipFree / event or stream creation: all per-batch path state (ray streams, hits,
+ * history, path values, counters, traversal overflow stacks) lives in one static device array of
+ * mi_noalloc_workspace_bytes() = 64 MiB that every GPU running this library holds until the process ends.
+ * The frame is rendered in as many batches as that takes (C3 at 1080p: 200+ batches, several times slower
+ * than mi_render_device: it is the entry point for those who cannot call the other).
+ * Limits: MI_ERR_INVALID with a message naming the sizes when even the smallest batch (64 pixels x
+ * samples_per_dim^2 paths at `depth`, plus the overflow stacks the resident tree needs) does not fit —
+ * e.g. depth 5 allows samples_per_dim up to ~40, depth 62 up to ~16; count_work is not supported.
+ * stats != NULL: the stream is synchronised and *stats filled (ms_total, rays_cast, paths, batches; no
+ * per-kernel times).  stats == NULL: the work is only ENQUEUED on `stream` (kernel launches and
+ * hipMemsetAsync, nothing else) and the call returns without synchronising.
+ * Every context on a GPU shares that GPU's array, and a call finds the previous call's contents in it
+ * (what must start at zero is cleared on the stream): calls that overlap on one GPU — two contexts, two
+ * streams, or a call made while an un-synchronised earlier one is still running on another stream —
+ * RACE.  Calls on the same stream are ordered and safe. */
+mi_status mi_render_device_noalloc(mi_ctx *ctx, const mi_render_params *params,
+                                   void *d_rgba_mean, void *d_rgba8, void *stream,
+                                   mi_stats *stats);
+
+/* Size in bytes of the static workspace of mi_render_device_noalloc (per GPU).  No counterpart
+ * in the reference. */
+int64_t mi_noalloc_workspace_bytes(void);
+
 /* Number of local pixel slots (owned tiles * tile_w * tile_h) of a shard. */
 int64_t mi_shard_pixels(const mi_render_params *params);
 

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -33,6 +34,31 @@ static mi_status fail(mi_status st, const char *fmt, ...) {
             return fail(e_ == hipErrorOutOfMemory ? MI_ERR_OOM : MI_ERR_HIP, "%s failed: %s (%s:%d)", #call, \
                         hipGetErrorString(e_), __FILE__, __LINE__);                                        \
     } while (0)
+
+// ---- workspace of the entry point that allocates nothing (mi_render_device_noalloc) ---------------------
+// All per-batch path state (ray streams, hits, history, path values, counters, overflow stacks, totals) in ONE
+// file-scope device array, here called `scratch`: MI_NOALLOC_BYTES on every GPU this library's code object is
+// loaded on, until the process ends.  In host code the array's NAME is only a stand-in: the address the kernels
+// need is asked for per device (hipGetSymbolAddress, noalloc_workspace() below) and passed to them as an
+// argument, like the grown buffers of mi_render_device.
+#define MI_NOALLOC_BYTES ((size_t)64 << 20)
+static __device__ __align__(256) unsigned char scratch[MI_NOALLOC_BYTES];
+static std::mutex g_ws_mutex;
+static unsigned char *g_ws_ptr[64]; // per device, filled on the first mi_ctx_create on that device
+
+// Called with `device` current (mi_ctx_create).  Each GPU holds its own copy of the array at its own address.
+static mi_status noalloc_workspace(int device, unsigned char **out) {
+    if (device < 0 || device >= 64) return fail(MI_ERR_NO_DEVICE, "device %d beyond the workspace table", device);
+    std::lock_guard<std::mutex> lock(g_ws_mutex);
+    if (!g_ws_ptr[device]) {
+        void *ptr = nullptr;
+        hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !ptr) return fail(MI_ERR_HIP, "hipGetSymbolAddress(scratch) failed on device %d: %s", device, hipGetErrorString(e));
+        g_ws_ptr[device] = (unsigned char *)ptr;
+    }
+    *out = g_ws_ptr[device];
+    return MI_OK;
+}
 
 namespace {
 
@@ -69,6 +95,8 @@ struct mi_ctx {
     DevBuf out_mean, out_rgba8, out_rgb8, out_mean_frame, probe_i, probe_t, probe_n;
     std::vector<hipEvent_t> ev;
     uint64_t *h_totals = nullptr; // pinned
+    unsigned char *ws = nullptr;  // this device's copy of the static workspace of mi_render_device_noalloc
+    int max_stack = MI_MAX_STACK; // traversal stack entries a ray can need in the resident tree (3 per level of the 4-wide tree)
     // tuning knobs (defaults measured on MI355X, overridable through the environment)
     int extend_wg_per_cu = 7;   // MI_TRACER_EXTEND_WG_PER_CU: persistent workgroups of k_extend per CU (clamped by the occupancy query)
     int extend_wg_primary = 6;  // the same for the level-0 variant, which holds more registers
@@ -91,13 +119,16 @@ static const int kTotals = 64;
 static const int kLevelWords = MI_SUB * MI_CNT_STRIDE; // counter j of a level at word j * MI_CNT_STRIDE
 static const int kCounterWords = (kMaxLevels + 1) * kLevelWords + MI_CNT_STRIDE;
 
+// Stack entries a ray can need in a tree of `depth2` levels of binary interior nodes: the 4-wide tree has
+// ceil(depth2 / 2) levels and a node visit pushes at most three refs (+ 3 of margin).
+static int stack_need(int depth2) { return std::min(MI_MAX_STACK, 3 * ((depth2 + 1) / 2) + 3); }
 static int extend_grid(const mi_ctx *c) { return c->n_cu * c->extend_wg_per_cu; }
 // Workgroups of the largest persistent launch (k_extend, its level-0 variant, k_tail): every one of their
 // threads owns a column of the global overflow stack, indexed by blockIdx.x * MI_BLOCK + threadIdx.x.
 static int stack_grid(const mi_ctx *c) { return c->n_cu * std::max(c->extend_wg_per_cu, std::max(c->extend_wg_primary, c->tail_wg_per_cu)); }
 static size_t stack_bytes(const mi_ctx *c) { return (size_t)(MI_MAX_STACK - MI_LDS_STACK) * stack_grid(c) * MI_BLOCK * 4; }
 
-MI_API int mi_abi_version(void) { return 9; }
+MI_API int mi_abi_version(void) { return 10; }
 MI_API const char *mi_last_error(void) { return g_err.c_str(); }
 
 MI_API mi_status mi_ctx_create(int device_id, mi_ctx **out) {
@@ -149,10 +180,21 @@ MI_API mi_status mi_ctx_create(int device_id, mi_ctx **out) {
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_tail, MI_BLOCK, 0) == hipSuccess && occ > 0)
         c->tail_wg_per_cu = std::min(occ, c->extend_wg_per_cu);
     c->tail_wg_per_cu = env_int("MI_TRACER_TAIL_WG_PER_CU", 1, 16, c->tail_wg_per_cu);
+    {   // this device's address of the static workspace, and the two events that bracket a render: nothing is
+        // left to create or allocate when mi_render_device_noalloc runs
+        mi_status wsr = noalloc_workspace(device_id, &c->ws);
+        if (wsr != MI_OK) { delete c; return wsr; }
+        for (int i = 0; i < 2; i++) {
+            hipEvent_t ev;
+            hipError_t ee = hipEventCreate(&ev);
+            if (ee != hipSuccess) { for (hipEvent_t x : c->ev) (void)hipEventDestroy(x); delete c; return fail(MI_ERR_HIP, "hipEventCreate failed: %s", hipGetErrorString(ee)); }
+            c->ev.push_back(ev);
+        }
+    }
     hipError_t es = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-    if (es != hipSuccess) { delete c; return fail(MI_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(es)); }
+    if (es != hipSuccess) { for (hipEvent_t x : c->ev) (void)hipEventDestroy(x); delete c; return fail(MI_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(es)); }
     es = hipHostMalloc((void **)&c->h_totals, kTotals * sizeof(uint64_t), hipHostMallocDefault);
-    if (es != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return fail(MI_ERR_HIP, "hipHostMalloc failed: %s", hipGetErrorString(es)); }
+    if (es != hipSuccess) { for (hipEvent_t x : c->ev) (void)hipEventDestroy(x); (void)hipStreamDestroy(c->stream); delete c; return fail(MI_ERR_HIP, "hipHostMalloc failed: %s", hipGetErrorString(es)); }
     *out = c;
     return MI_OK;
 }
@@ -192,7 +234,8 @@ static mi_status validate_prims(const mi_scene_soa *s) {
     return MI_OK;
 }
 
-static mi_status validate_scene(const mi_scene_soa *s) {
+static mi_status validate_scene(const mi_scene_soa *s, int *depth_out) {
+    *depth_out = 0;
     const uint64_t n_prim = (uint64_t)s->n_tri + s->n_sph;
     mi_status ps = validate_prims(s);
     if (ps != MI_OK) return ps;
@@ -217,6 +260,7 @@ static mi_status validate_scene(const mi_scene_soa *s) {
         auto [ref, depth] = st.back();
         st.pop_back();
         if (depth > MI_MAX_DEPTH) return fail(MI_ERR_INVALID, "scene: BVH deeper than %d", MI_MAX_DEPTH);
+        *depth_out = std::max(*depth_out, depth);
         if (seen_node[ref]++) return fail(MI_ERR_INVALID, "scene: node %d referenced twice", ref);
         for (int c = 0; c < 2; c++) {
             int32_t ch;
@@ -415,7 +459,8 @@ static mi_status install_bvh4(mi_ctx *c, const float *nodes2, int32_t root2) {
 MI_API mi_status mi_scene_upload(mi_ctx *c, const mi_scene_soa *s) {
     if (!c || !s) return fail(MI_ERR_INVALID, "mi_scene_upload: NULL argument");
     c->has_scene = false; // a rejected or failed upload leaves the context without a scene
-    mi_status vs = validate_scene(s);
+    int depth2 = 0;
+    mi_status vs = validate_scene(s, &depth2);
     if (vs != MI_OK) return vs;
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(c->nodes.ensure(std::max<size_t>((size_t)s->n_nodes * 64, 16)));
@@ -426,6 +471,7 @@ MI_API mi_status mi_scene_upload(mi_ctx *c, const mi_scene_soa *s) {
     c->n_nodes = s->n_nodes;
     mi_status cs = install_bvh4(c, s->nodes, (uint64_t)s->n_tri + s->n_sph > 0 ? s->root_ref : ~0);
     if (cs != MI_OK) return cs;
+    c->max_stack = stack_need(depth2);
     c->has_scene = true;
     return MI_OK;
 }
@@ -523,6 +569,7 @@ MI_API mi_status mi_scene_upload_build(mi_ctx *c, const mi_scene_soa *s, const f
         c->root_ref2 = ~0;
         mi_status cs = install_bvh4(c, nullptr, ~0);
         if (cs != MI_OK) return cs;
+        c->max_stack = stack_need(0);
         c->has_scene = true;
         return MI_OK;
     }
@@ -536,7 +583,7 @@ MI_API mi_status mi_scene_upload_build(mi_ctx *c, const mi_scene_soa *s, const f
     const bool use_ploc = !(builder && !strcmp(builder, "lbvh"));
     int32_t root2 = 0, root4 = 0;
     uint32_t n4 = 0;
-    int treelet_n = 0;
+    int treelet_n = 0, built_depth = 0;
     auto body = [&]() -> mi_status {
         HIPCHK(verts.ensure(std::max<size_t>((size_t)s->n_tri * 36, 16)));
         if (s->n_tri) HIPCHK(hipMemcpyAsync(verts.p, tri_verts, (size_t)s->n_tri * 36, hipMemcpyHostToDevice, st));
@@ -677,6 +724,7 @@ MI_API mi_status mi_scene_upload_build(mi_ctx *c, const mi_scene_soa *s, const f
         float ms = 0;
         HIPCHK(hipEventElapsedTime(&ms, e0, e1));
         if (h_root > MI_MAX_DEPTH) return fail(MI_ERR_INVALID, "device-built BVH is %d levels deep (limit %d)", h_root, MI_MAX_DEPTH);
+        built_depth = h_root;
         if (stats) {
             double a = 2.0 * (dx * dy + dy * dz + dz * dx);
             if (use_ploc) { const double px = dx + 2.0 * pad, py = dy + 2.0 * pad, pz = dz + 2.0 * pad; a = 2.0 * (px * py + py * pz + pz * px); } // its boxes are summed padded
@@ -697,6 +745,7 @@ MI_API mi_status mi_scene_upload_build(mi_ctx *c, const mi_scene_soa *s, const f
     c->sc.treelet_count = treelet_n;
     mi_status qs = quantize_nodes4(c, n4 + (uint32_t)treelet_n);
     if (qs != MI_OK) return qs;
+    c->max_stack = stack_need(built_depth);
     c->has_scene = true;
     return MI_OK;
 }
@@ -767,82 +816,88 @@ __global__ void k_sum_counts(const uint32_t *counts, int n, uint64_t *totals, co
     }
 }
 
-MI_API mi_status mi_render_device(mi_ctx *c, const mi_render_params *p, void *d_rgba_mean, void *d_rgba8, void *stream_v,
-                                  mi_stats *stats) {
-    if (!c) return fail(MI_ERR_INVALID, "ctx is NULL");
-    if (!c->has_scene) return fail(MI_ERR_NO_SCENE, "mi_render: no scene uploaded");
-    ShardGeom g;
-    mi_status gs = make_geom(p, g);
-    if (gs != MI_OK) return gs;
-    HIPCHK(hipSetDevice(c->device));
-    hipStream_t st = stream_v ? (hipStream_t)stream_v : c->stream;
+// Sizes of one wavefront batch of npix_b pixels (cap = npix_b * spp path slots).
+struct BatchPlan {
+    int64_t npix_b;
+    size_t cap;        // path slots
+    int sgrid;         // workgroups of k_shade
+    uint32_t segcap;   // stream positions per sub-stream
+    size_t stream_cap; // stream positions in all
+    int hist_levels;
+};
+// Ray streams: MI_SUB sub-streams of `segcap` positions each.  Shade workgroup b appends to sub-stream
+// b % MI_SUB and handles at most ceil((n_virtual + 255) / sgrid) + 256 rays (grid-stride loop over 256-ray
+// groups), n_virtual <= cap + 64*MI_SUB.
+static mi_status plan_batch(const mi_ctx *c, int64_t npix_b, int spp, int depth, BatchPlan &bp) {
+    const int64_t cap64 = npix_b * spp;
+    if (cap64 >= ((int64_t)1 << 32) - 64) return fail(MI_ERR_INVALID, "batch too large (samples_per_dim too high)");
+    bp.npix_b = npix_b;
+    bp.cap = (size_t)cap64;
+    bp.hist_levels = std::max(1, depth + 1);
+    bp.sgrid = (int)std::min<int64_t>((int64_t)c->n_cu * c->shade_wg_per_cu, (int64_t)(bp.cap + MI_BLOCK - 1) / MI_BLOCK);
+    const size_t wg_per_sub = ((size_t)bp.sgrid + MI_SUB - 1) / MI_SUB;
+    const size_t segcap64 = (wg_per_sub * ((bp.cap + 64 * MI_SUB + MI_BLOCK + (size_t)bp.sgrid - 1) / (size_t)bp.sgrid + MI_BLOCK) + 63) / 64 * 64;
+    if (segcap64 * MI_SUB >= ((size_t)1 << 32)) return fail(MI_ERR_INVALID, "batch too large for 32-bit stream positions");
+    bp.segcap = (uint32_t)segcap64;
+    bp.stream_cap = segcap64 * MI_SUB;
+    return MI_OK;
+}
+// Device memory of a batch and the grids of the persistent kernels (the overflow stacks in `ovf` have one
+// column per thread of the largest of them).
+struct PathMem {
+    float4 *ray_o[2], *ray_d[2], *thr[2], *hits, *path_out, *hist;
+    uint32_t *counters;
+    int *ovf;
+    uint64_t *totals;
+    int egrid, egrid0, tgrid; // workgroups of k_extend (levels >= 1), of its level-0 variant, of k_tail
+};
+
+// The wavefront loop over all batches of a shard: shared by mi_render_device (buffers grown on demand) and
+// mi_render_device_noalloc (buffers carved out of the static workspace).  timed: per-launch events may be
+// created; sync: wait for the stream and fill *stats (otherwise the work is only enqueued).
+static mi_status render_batches(mi_ctx *c, const mi_render_params *p, const ShardGeom &g, const BatchPlan &bp, const PathMem &m, void *d_rgba_mean,
+                                void *d_rgba8, hipStream_t st, mi_stats *stats, bool timed, bool sync) {
     const int64_t local = shard_pixels(g);
     const int spp = g.samples * g.samples;
     const int levels = p->depth + 2; // rays per path <= D+2 (CpuTracer.cu:119-131)
-    // default batch: 64 Mi path slots, fewer for deep paths so that the per-batch state (32 B of history per
-    // level, two ray streams, hits, path values: ~128 B + 32 B per level and slot) stays below ~32 GB
-    const int64_t per_slot = 128 + 32 * (int64_t)std::max(1, p->depth + 1);
-    int64_t want = p->batch_paths > 0 ? p->batch_paths : std::min<int64_t>((int64_t)64 << 20, std::max<int64_t>((int64_t)1 << 20, ((int64_t)32 << 30) / per_slot));
-    want = std::min<int64_t>(want, (int64_t)1 << 30);
-    int64_t npix_b = std::max<int64_t>(64, want / spp / 64 * 64);
-    npix_b = std::min(npix_b, std::max<int64_t>(local, 1));
-    const int64_t cap64 = npix_b * spp;
-    if (cap64 >= ((int64_t)1 << 32) - 64) return fail(MI_ERR_INVALID, "batch too large (samples_per_dim too high)");
-    const size_t cap = (size_t)cap64;
-    const int hist_levels = std::max(1, p->depth + 1);
+    const int64_t npix_b = bp.npix_b;
+    const size_t cap = bp.cap;
+    const int hist_levels = bp.hist_levels;
     const bool count_work = p->count_work != 0;
-    // Ray streams: MI_SUB sub-streams of `segcap` positions each.  Shade workgroup b appends to
-    // sub-stream b % MI_SUB and handles at most
-    // ceil((n_virtual + 255) / sgrid) + 256 rays (grid-stride loop over 256-ray groups), n_virtual <= cap + 64*MI_SUB.
-    const int sgrid = (int)std::min<int64_t>((int64_t)c->n_cu * c->shade_wg_per_cu, (int64_t)(cap + MI_BLOCK - 1) / MI_BLOCK);
-    const size_t wg_per_sub = ((size_t)sgrid + MI_SUB - 1) / MI_SUB;
-    const size_t segcap64 = (wg_per_sub * ((cap + 64 * MI_SUB + MI_BLOCK + (size_t)sgrid - 1) / (size_t)sgrid + MI_BLOCK) + 63) / 64 * 64;
-    if (segcap64 * MI_SUB >= ((size_t)1 << 32)) return fail(MI_ERR_INVALID, "batch too large for 32-bit stream positions");
-    const uint32_t segcap = (uint32_t)segcap64;
-    const size_t stream_cap = segcap64 * MI_SUB;
-    for (int i = 0; i < 2; i++) {
-        HIPCHK(c->ray_o[i].ensure(stream_cap * 16));
-        HIPCHK(c->ray_d[i].ensure(stream_cap * 16));
-        HIPCHK(c->thr[i].ensure(stream_cap * 16));
-    }
-    HIPCHK(c->hits.ensure(stream_cap * 16));
-    HIPCHK(c->path_out.ensure(cap * 16));
-    HIPCHK(c->hist.ensure(cap * 32 * hist_levels));
-    HIPCHK(c->counters.ensure(kCounterWords * 4));
-    const int egrid = extend_grid(c);
-    HIPCHK(c->ovf.ensure(stack_bytes(c)));
-    HIPCHK(c->totals.ensure(kTotals * 8));
+    const int sgrid = bp.sgrid;
+    const uint32_t segcap = bp.segcap;
     const int64_t n_batches = local > 0 ? (local + npix_b - 1) / npix_b : 0;
     const size_t n_ev = 2 + (size_t)n_batches * levels * 4;
-    const bool per_launch = n_ev <= 4096; // per-launch timing only while the event count stays modest
-    mi_status es = get_events(c, per_launch ? n_ev : 2);
-    if (es != MI_OK) return es;
+    const bool per_launch = timed && n_ev <= 4096; // per-launch timing only while the event count stays modest
+    if (timed) {
+        mi_status es = get_events(c, per_launch ? n_ev : 2);
+        if (es != MI_OK) return es;
+    }
 
-    uint32_t *cnt = c->counters.as<uint32_t>();               // cnt[k*kLevelWords + j*MI_CNT_STRIDE] = rays in sub-stream j of level k
+    uint32_t *cnt = m.counters;                                   // cnt[k*kLevelWords + j*MI_CNT_STRIDE] = rays in sub-stream j of level k
     uint32_t *tail_level = cnt + (kMaxLevels + 1) * kLevelWords;  // 0, or the level at which k_tail took over
-    const RayStream rs[2] = {{c->ray_o[0].as<float4>(), c->ray_d[0].as<float4>(), c->thr[0].as<float4>(), segcap},
-                             {c->ray_o[1].as<float4>(), c->ray_d[1].as<float4>(), c->thr[1].as<float4>(), segcap}};
-    HIPCHK(hipMemsetAsync(c->totals.p, 0, kTotals * 8, st));
-    HIPCHK(hipEventRecord(c->ev[0], st));
+    const RayStream rs[2] = {{m.ray_o[0], m.ray_d[0], m.thr[0], segcap}, {m.ray_o[1], m.ray_d[1], m.thr[1], segcap}};
+    HIPCHK(hipMemsetAsync(m.totals, 0, kTotals * 8, st));
+    if (sync) HIPCHK(hipEventRecord(c->ev[0], st));
     size_t evi = 2;
     for (int64_t b = 0; b < n_batches; b++) {
         const uint32_t pix0 = (uint32_t)(b * npix_b);
         const uint32_t np = (uint32_t)std::min<int64_t>(npix_b, local - (int64_t)pix0);
         const int64_t nslots = (int64_t)np * spp;
-        const uint32_t rot0 = deal_rotation((uint32_t)(c->n_cu * c->extend_wg_primary) * (MI_BLOCK / 64), np, spp);
+        const uint32_t rot0 = deal_rotation((uint32_t)m.egrid0 * (MI_BLOCK / 64), np, spp);
         HIPCHK(hipMemsetAsync(cnt, 0, kCounterWords * 4, st));
         for (int k = 0; k < levels; k++) {
             const RayStream &sin = rs[k & 1], &sout = rs[(k + 1) & 1];
-            unsigned long long *ws = count_work ? c->totals.as<unsigned long long>() + 2 : nullptr;
+            unsigned long long *ws = count_work ? (unsigned long long *)m.totals + 2 : nullptr;
             if (per_launch) HIPCHK(hipEventRecord(c->ev[evi++], st)); // 4 events per level: tail | extend | shade
             if (k >= 1 && c->tail_threshold > 0 && !count_work)
-                hipLaunchKernelGGL(k_tail, dim3(c->n_cu * c->tail_wg_per_cu), dim3(MI_BLOCK), 0, st, c->sc, g, pix0, np, k, p->depth, p->seed, sin, cnt + k * kLevelWords,
-                                   (uint32_t)c->tail_threshold, tail_level, c->hist.as<float4>(), cap, (size_t)hist_levels * cap, c->path_out.as<float4>(), c->ovf.as<int>(),
-                                   c->totals.as<unsigned long long>() + 7, c->shade_min, c->tail_refill);
+                hipLaunchKernelGGL(k_tail, dim3(m.tgrid), dim3(MI_BLOCK), 0, st, c->sc, g, pix0, np, k, p->depth, p->seed, sin, cnt + k * kLevelWords,
+                                   (uint32_t)c->tail_threshold, tail_level, m.hist, cap, (size_t)hist_levels * cap, m.path_out, m.ovf,
+                                   (unsigned long long *)m.totals + 7, c->shade_min, c->tail_refill);
             if (per_launch) HIPCHK(hipEventRecord(c->ev[evi++], st));
 #define MI_EXTEND_ARGS(PRIM)                                                                                                   \
-    dim3((PRIM) ? c->n_cu * c->extend_wg_primary : egrid), dim3(MI_BLOCK), 0, st, c->sc, (PRIM) ? (const uint32_t *)nullptr : cnt + k * kLevelWords,                   \
-        (PRIM) ? (uint32_t)nslots : 0u, segcap, sin.o, sin.d, c->hits.as<float4>(), c->ovf.as<int>(), ws,                          \
+    dim3((PRIM) ? m.egrid0 : m.egrid), dim3(MI_BLOCK), 0, st, c->sc, (PRIM) ? (const uint32_t *)nullptr : cnt + k * kLevelWords,                   \
+        (PRIM) ? (uint32_t)nslots : 0u, segcap, sin.o, sin.d, m.hits, m.ovf, ws,                          \
         (PRIM) ? c->refill_primary : c->refill_min, c->leaf_min, g, pix0, np, cnt, tail_level, k, (PRIM) ? rot0 : 0u
             if (k == 0) {
                 if (count_work) hipLaunchKernelGGL((k_extend<true, true>), MI_EXTEND_ARGS(true));
@@ -854,19 +909,20 @@ MI_API mi_status mi_render_device(mi_ctx *c, const mi_render_params *p, void *d_
 #undef MI_EXTEND_ARGS
             if (per_launch) HIPCHK(hipEventRecord(c->ev[evi++], st));
 #define MI_SHADE_ARGS                                                                                                          \
-    dim3(sgrid), dim3(MI_BLOCK), 0, st, c->sc, g, pix0, np, k, p->depth - k, p->seed, sin, cnt + k * kLevelWords, c->hits.as<float4>(),         \
-        c->hist.as<float4>(), cap, (size_t)hist_levels * cap, c->path_out.as<float4>(), sout, cnt + (k + 1) * kLevelWords, (uint32_t)nslots, tail_level
+    dim3(sgrid), dim3(MI_BLOCK), 0, st, c->sc, g, pix0, np, k, p->depth - k, p->seed, sin, cnt + k * kLevelWords, m.hits,         \
+        m.hist, cap, (size_t)hist_levels * cap, m.path_out, sout, cnt + (k + 1) * kLevelWords, (uint32_t)nslots, tail_level
             if (k == 0) hipLaunchKernelGGL(k_shade<true>, MI_SHADE_ARGS);
             else hipLaunchKernelGGL(k_shade<false>, MI_SHADE_ARGS);
 #undef MI_SHADE_ARGS
             if (per_launch) HIPCHK(hipEventRecord(c->ev[evi++], st));
         }
-        hipLaunchKernelGGL(k_resolve, dim3((np + MI_BLOCK - 1) / MI_BLOCK), dim3(MI_BLOCK), 0, st, g, pix0, np, c->path_out.as<float4>(),
+        hipLaunchKernelGGL(k_resolve, dim3((np + MI_BLOCK - 1) / MI_BLOCK), dim3(MI_BLOCK), 0, st, g, pix0, np, m.path_out,
                            (float4 *)d_rgba_mean, (uchar4 *)d_rgba8);
-        hipLaunchKernelGGL(k_sum_counts, dim3(1), dim3(64), 0, st, cnt, levels, c->totals.as<uint64_t>(), tail_level);
+        hipLaunchKernelGGL(k_sum_counts, dim3(1), dim3(64), 0, st, cnt, levels, m.totals, tail_level);
     }
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(c->h_totals, c->totals.p, kTotals * 8, hipMemcpyDeviceToHost, st));
+    if (!sync) return MI_OK;
+    HIPCHK(hipMemcpyAsync(c->h_totals, m.totals, kTotals * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipEventRecord(c->ev[1], st));
     HIPCHK(hipStreamSynchronize(st));
     if (stats) {
@@ -922,6 +978,110 @@ MI_API mi_status mi_render_device(mi_ctx *c, const mi_render_params *p, void *d_
         }
     }
     return MI_OK;
+}
+
+MI_API mi_status mi_render_device(mi_ctx *c, const mi_render_params *p, void *d_rgba_mean, void *d_rgba8, void *stream_v,
+                                  mi_stats *stats) {
+    if (!c) return fail(MI_ERR_INVALID, "ctx is NULL");
+    if (!c->has_scene) return fail(MI_ERR_NO_SCENE, "mi_render: no scene uploaded");
+    ShardGeom g;
+    mi_status gs = make_geom(p, g);
+    if (gs != MI_OK) return gs;
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t st = stream_v ? (hipStream_t)stream_v : c->stream;
+    const int64_t local = shard_pixels(g);
+    const int spp = g.samples * g.samples;
+    // default batch: 64 Mi path slots, fewer for deep paths so that the per-batch state (32 B of history per
+    // level, two ray streams, hits, path values: ~128 B + 32 B per level and slot) stays below ~32 GB
+    const int64_t per_slot = 128 + 32 * (int64_t)std::max(1, p->depth + 1);
+    int64_t want = p->batch_paths > 0 ? p->batch_paths : std::min<int64_t>((int64_t)64 << 20, std::max<int64_t>((int64_t)1 << 20, ((int64_t)32 << 30) / per_slot));
+    want = std::min<int64_t>(want, (int64_t)1 << 30);
+    int64_t npix_b = std::max<int64_t>(64, want / spp / 64 * 64);
+    npix_b = std::min(npix_b, std::max<int64_t>(local, 1));
+    BatchPlan bp;
+    mi_status ps = plan_batch(c, npix_b, spp, p->depth, bp);
+    if (ps != MI_OK) return ps;
+    for (int i = 0; i < 2; i++) {
+        HIPCHK(c->ray_o[i].ensure(bp.stream_cap * 16));
+        HIPCHK(c->ray_d[i].ensure(bp.stream_cap * 16));
+        HIPCHK(c->thr[i].ensure(bp.stream_cap * 16));
+    }
+    HIPCHK(c->hits.ensure(bp.stream_cap * 16));
+    HIPCHK(c->path_out.ensure(bp.cap * 16));
+    HIPCHK(c->hist.ensure(bp.cap * 32 * bp.hist_levels));
+    HIPCHK(c->counters.ensure(kCounterWords * 4));
+    HIPCHK(c->ovf.ensure(stack_bytes(c)));
+    HIPCHK(c->totals.ensure(kTotals * 8));
+    PathMem m;
+    for (int i = 0; i < 2; i++) { m.ray_o[i] = c->ray_o[i].as<float4>(); m.ray_d[i] = c->ray_d[i].as<float4>(); m.thr[i] = c->thr[i].as<float4>(); }
+    m.hits = c->hits.as<float4>(); m.path_out = c->path_out.as<float4>(); m.hist = c->hist.as<float4>();
+    m.counters = c->counters.as<uint32_t>(); m.ovf = c->ovf.as<int>(); m.totals = c->totals.as<uint64_t>();
+    m.egrid = extend_grid(c); m.egrid0 = c->n_cu * c->extend_wg_primary; m.tgrid = c->n_cu * c->tail_wg_per_cu;
+    return render_batches(c, p, g, bp, m, d_rgba_mean, d_rgba8, st, stats, true, true);
+}
+
+// ---- the entry point that allocates nothing (workspace: see `scratch` at the top of this file) ----------
+MI_API int64_t mi_noalloc_workspace_bytes(void) { return (int64_t)MI_NOALLOC_BYTES; }
+
+MI_API mi_status mi_render_device_noalloc(mi_ctx *c, const mi_render_params *p, void *d_rgba_mean, void *d_rgba8, void *stream_v,
+                                          mi_stats *stats) {
+    if (!c) return fail(MI_ERR_INVALID, "ctx is NULL");
+    if (!c->has_scene) return fail(MI_ERR_NO_SCENE, "mi_render_device_noalloc: no scene uploaded");
+    if (!c->ws) return fail(MI_ERR_HIP, "mi_render_device_noalloc: the context has no workspace address");
+    if (p && p->count_work) return fail(MI_ERR_INVALID, "mi_render_device_noalloc: count_work is not supported");
+    ShardGeom g;
+    mi_status gs = make_geom(p, g);
+    if (gs != MI_OK) return gs;
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t st = stream_v ? (hipStream_t)stream_v : c->stream;
+    const int64_t local = shard_pixels(g);
+    const int spp = g.samples * g.samples;
+    // Fixed part: totals, counters, overflow stacks.  The batches are small, so two persistent workgroups per CU
+    // are plenty; the stack columns are only as long as the resident tree can make a stack (3 pushes per level of
+    // the 4-wide tree, MI_LDS_STACK of them in LDS).
+    auto up256 = [](size_t x) { return (x + 255) / 256 * 256; };
+    PathMem m;
+    const int wg = std::min(2, std::min(c->extend_wg_per_cu, std::min(c->extend_wg_primary, c->tail_wg_per_cu)));
+    m.egrid = m.egrid0 = m.tgrid = c->n_cu * wg;
+    const size_t ovf_entries = (size_t)std::max(0, c->max_stack - MI_LDS_STACK);
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { unsigned char *q = c->ws + off; off += up256(bytes); return q; };
+    m.totals = (uint64_t *)carve(kTotals * 8);
+    m.counters = (uint32_t *)carve(kCounterWords * 4);
+    m.ovf = (int *)carve(std::max<size_t>(ovf_entries * (size_t)m.egrid * MI_BLOCK * 4, 256));
+    const size_t fixed = off;
+    // The rest holds one batch: the largest multiple of 64 pixels that fits (per slot: two ray streams of three
+    // float4 records, hits, path value, 32 B of history per level; plan_batch has the exact stream sizes).
+    auto batch_bytes = [&](const BatchPlan &b) { return 7 * up256(b.stream_cap * 16) + up256(b.cap * 16) + up256(b.cap * 32 * (size_t)b.hist_levels); };
+    BatchPlan bp;
+    int64_t lo = 0, hi = (std::max<int64_t>(local, 1) + 63) / 64; // in units of 64 pixels; lo fits (0 = nothing), find the largest that fits
+    while (lo < hi) {
+        const int64_t mid = (lo + hi + 1) / 2;
+        BatchPlan t;
+        const bool fits = plan_batch(c, mid * 64, spp, p->depth, t) == MI_OK && fixed + batch_bytes(t) <= MI_NOALLOC_BYTES;
+        if (fits) lo = mid; else hi = mid - 1;
+    }
+    if (lo == 0) {
+        BatchPlan t;
+        size_t need = 0;
+        if (plan_batch(c, 64, spp, p->depth, t) == MI_OK) need = fixed + batch_bytes(t);
+        return fail(MI_ERR_INVALID, "mi_render_device_noalloc: the smallest batch (64 pixels x %d samples, depth %d, tree stack %d) needs %zu bytes, "
+                    "the static workspace has %zu: use mi_render_device", spp, p->depth, c->max_stack, need, (size_t)MI_NOALLOC_BYTES);
+    }
+    mi_status ps = plan_batch(c, std::min<int64_t>(lo * 64, std::max<int64_t>(local, 1)), spp, p->depth, bp);
+    if (ps != MI_OK) return ps;
+    for (int i = 0; i < 2; i++) {
+        m.ray_o[i] = (float4 *)carve(bp.stream_cap * 16);
+        m.ray_d[i] = (float4 *)carve(bp.stream_cap * 16);
+        m.thr[i] = (float4 *)carve(bp.stream_cap * 16);
+    }
+    m.hits = (float4 *)carve(bp.stream_cap * 16);
+    m.path_out = (float4 *)carve(bp.cap * 16);
+    m.hist = (float4 *)carve(bp.cap * 32 * (size_t)bp.hist_levels);
+    if (off > MI_NOALLOC_BYTES) return fail(MI_ERR_INVALID, "mi_render_device_noalloc: internal sizing error (%zu > %zu)", off, (size_t)MI_NOALLOC_BYTES);
+    // Every call on this GPU shares the array and finds the last call's contents in it: what must start at zero
+    // (totals, counters) is cleared by render_batches on the stream; everything else is written before it is read.
+    return render_batches(c, p, g, bp, m, d_rgba_mean, d_rgba8, st, stats, false, stats != nullptr);
 }
 
 MI_API mi_status mi_render(mi_ctx *c, const mi_render_params *p, float *rgba_mean_out, uint8_t *rgb8_out, mi_stats *stats) {

@@ -109,6 +109,13 @@ class Context:
         N.check(N.mi.mi_render_device(self._h, C.byref(params), d_mean_ptr, d_rgba8_ptr, stream, C.byref(st)))
         return st
 
+    def render_device_noalloc(self, params, d_mean_ptr, d_rgba8_ptr, stream=None, want_stats=True):
+        """mi_render_device_noalloc: same outputs from the static workspace, no allocation.  want_stats=False only
+        enqueues the work on `stream` (the caller synchronises)."""
+        st = N.Stats() if want_stats else None
+        N.check(N.mi.mi_render_device_noalloc(self._h, C.byref(params), d_mean_ptr, d_rgba8_ptr, stream, C.byref(st) if want_stats else None))
+        return st
+
     def assemble_rgb8(self, params, d_gathered_ptr, shard_stride_pixels):
         rgb = np.zeros((params.height, params.width, 3), np.uint8)
         N.check(N.mi.mi_assemble_rgb8(self._h, C.byref(params), d_gathered_ptr, shard_stride_pixels, rgb.ctypes.data))

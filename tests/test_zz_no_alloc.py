@@ -1,0 +1,79 @@
+"""mi_render_device_noalloc — the one entry point that allocates nothing (static 64-MiB workspace) — against
+mi_render_device, through the C-ABI, bit for bit: two calls in a row, the second with a smaller input (it finds
+the first call's contents in the workspace), single- and multi-batch frames, the enqueue-only mode, a device-built
+tree, a shard, and the rejection of inputs whose smallest batch does not fit."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import pathtracer_amd as P
+from pathtracer_amd import _native as N
+from pathtracer_amd import scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def both(ctx, p, stream=None, want_stats=True):
+    n = P.shard_pixels(p)
+    dev = torch.device("cuda", 0)
+    outs = []
+    for noalloc in (False, True):
+        mean = torch.full((n, 4), -1.0, dtype=torch.float32, device=dev)
+        rgba = torch.full((n, 4), 7, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        if noalloc:
+            st = ctx.render_device_noalloc(p, mean.data_ptr(), rgba.data_ptr(), stream, want_stats)
+        else:
+            st = ctx.render_device(p, mean.data_ptr(), rgba.data_ptr(), stream)
+        torch.cuda.synchronize()   # the enqueue-only mode returns before the work is done
+        outs.append((mean.cpu().numpy(), rgba.cpu().numpy(), st))
+    (m0, r0, s0), (m1, r1, s1) = outs
+    assert np.array_equal(m0.view(np.uint32), m1.view(np.uint32)), "mean radiance differs"
+    assert np.array_equal(r0, r1), "RGBA8 differs"
+    if want_stats:
+        assert s1.rays_cast == s0.rays_cast and s1.paths == s0.paths
+    return s0, s1
+
+
+def test_noalloc_matches_render_device_twice_in_a_row(ctx, scenes_small):
+    assert N.mi.mi_noalloc_workspace_bytes() == 64 << 20
+    sc = scenes_small["cornell"]
+    ctx.upload(sc)
+    w, h = sc.image_size(512)
+    s0, s1 = both(ctx, P.Context.params(w, h, 2, 5, seed=3))          # 1 M paths: several batches from the workspace
+    assert s1.batches > 1 and s0.batches == 1
+    w2, h2 = sc.image_size(96)
+    s0, s1 = both(ctx, P.Context.params(w2, h2, 2, 5, seed=3))        # smaller input, one batch, stale workspace contents
+    assert s1.batches == 1
+    both(ctx, P.Context.params(w2, h2, 1, -1, seed=9))                # primary rays only
+    both(ctx, P.Context.params(33, 17, 3, 8, seed=4, tile=(5, 7), shard=(1, 3)))  # ragged tiles, a shard
+
+
+def test_noalloc_other_scenes_and_enqueue_only(ctx, scenes_small):
+    stream = torch.cuda.Stream()
+    for name, width, s, d in (("glass", 200, 2, 8), ("blob3", 160, 2, 4), ("simple", 128, 1, 2)):
+        sc = scenes_small[name]
+        ctx.upload(sc)
+        w, h = sc.image_size(width)
+        both(ctx, P.Context.params(w, h, s, d, seed=11), stream.cuda_stream, want_stats=False)
+    sc = scenes.blob_scene(5)                                          # 20 k triangles, device-built tree (deeper)
+    ctx.upload_build(sc)
+    w, h = sc.image_size(640)
+    s0, s1 = both(ctx, P.Context.params(w, h, 2, 5, seed=2))
+    assert s1.batches > 1
+    ctx.upload(sc)
+    both(ctx, P.Context.params(w, h, 1, 3, seed=2))
+
+
+def test_noalloc_rejects_what_cannot_fit(ctx, scenes_small):
+    ctx.upload(scenes_small["simple"])
+    p = P.Context.params(64, 64, 200, 5)                               # 64 pixels x 40000 samples: no batch fits 64 MiB
+    out = torch.zeros(P.shard_pixels(p) * 4, dtype=torch.uint8, device="cuda:0")
+    rc = N.mi.mi_render_device_noalloc(ctx._h, C.byref(p), None, out.data_ptr(), None, None)
+    assert rc == N.MI_ERR_INVALID and b"static workspace" in N.mi.mi_last_error()
+    pc = P.Context.params(16, 16, 1, 1, count_work=True)
+    assert N.mi.mi_render_device_noalloc(ctx._h, C.byref(pc), None, out.data_ptr(), None, None) == N.MI_ERR_INVALID
+    # and the regular entry point still takes it
+    ctx.render(P.Context.params(16, 16, 2, 1))
