@@ -20,7 +20,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
-VALU_PEAK_TFLOPS = 157.3     # fp32 vector peak (spec)
+VALU_PEAK_TFLOPS = 157.3     # fp32 vector peak (spec): 256 CUs x 4 SIMDs x 32 lanes/clock x 2 flop x 2.4 GHz
+VALU_PEAK_TLANEOPS = VALU_PEAK_TFLOPS / 2.0   # lane operations: one full wave64 VALU instruction per SIMD every 2 cycles
+L2_PEAK_GBS = 17000.0        # MI355X_MICROARCH.md: 16.8-18.8 TB/s chip-wide for rows served from the XCDs' L2s
 
 WORKLOADS = {
     # name: (scene builder, width, samples/dim, depth)   — SURVEY §8d
@@ -170,9 +172,46 @@ def main():
         print(f"[bench] assembled {world}-rank frame == single-rank frame: {same}", file=sys.stderr)
         if not same:
             raise SystemExit("assembled frame differs from the single-rank render")
+    # N > 1: where a step's time goes on every rank — three more steps OUTSIDE the timed region with a host sync
+    # after each phase (render of the shard | gather | assembly on rank 0)
+    phases = None
+    if world > 1:
+        acc = [0.0, 0.0, 0.0]
+        for _ in range(3):
+            torch.cuda.synchronize(); dist.barrier()
+            t_a = time.perf_counter()
+            ctx.render_device(params, None, rgba8.data_ptr(), stream)
+            t_b = time.perf_counter()
+            if args.backend == "gloo":
+                host_local.copy_(rgba8)
+                dist.gather(host_local, host_all, dst=0)
+            elif use_gather:
+                dist.gather(rgba8, list(gathered.view(world, -1).unbind(0)) if rank == 0 else None, dst=0)
+            else:
+                dist.all_gather_into_tensor(gathered, rgba8)
+            torch.cuda.synchronize()
+            t_c = time.perf_counter()
+            if rank == 0:
+                if args.backend == "gloo":
+                    gathered.copy_(torch.cat(host_all))
+                ctx.assemble_rgb8_device(params, gathered.data_ptr(), stride, frame.data_ptr(), stream)
+            t_d = time.perf_counter()
+            acc = [acc[0] + (t_b - t_a) * 1e3 / 3, acc[1] + (t_c - t_b) * 1e3 / 3, acc[2] + (t_d - t_c) * 1e3 / 3]
+        mine = torch.tensor(acc + [float(rays) / args.steps], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        allp = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allp, mine)
+        allp = torch.stack(allp).cpu().numpy()
+        phases = {"shard_ms": [float(x) for x in allp[:, 0]], "shard_ms_max": float(allp[:, 0].max()), "shard_ms_min": float(allp[:, 0].min()),
+                  "gather_ms": float(allp[0, 1]), "gather_ms_by_rank": [float(x) for x in allp[:, 1]], "assemble_ms": float(allp[0, 2]),
+                  "rays_per_step_by_rank": [float(x) for x in allp[:, 3]],
+                  "note": "3 extra steps outside the timed region, host sync after each phase; gather_ms on rank 0 includes waiting for the slowest shard"}
     if rank == 0:
-        # Roofline of the dominant kernel (k_extend) — algorithmic bytes of ITS OWN
-        # traversal, counted by the instrumented kernel variant outside the timed region.
+        # Roofline of the dominant kernel (k_extend).  What binds it is VALU issue with partly filled waves (DESIGN.md
+        # section 3): achieved = active-lane VALU operations per second = SQ_THREAD_CYCLES_VALU of one frame's k_extend
+        # launches (a property of code + workload, from the committed PMC pass, profiles/roofline_pmc.json) / the time
+        # of those launches measured LIVE here with HIP events; peak = every SIMD issuing a full wave64 instruction
+        # every 2 cycles = the guide's fp32 vector peak / 2 flop.  The algorithmic byte rate of SURVEY 8(d) is kept
+        # beside it as algorithmic_gbs (the scene is cache resident: not a roof that binds).
         pc = P.Context.params(w, h, samples, depth, seed=0, shard=(rank, world), batch_paths=args.batch_paths, count_work=True)
         stc = ctx.render_device(pc, None, rgba8.data_ptr(), stream)
         r = max(1, stc.rays_cast)
@@ -184,9 +223,39 @@ def main():
         rays_rank0_per_step = rays_ext / args.steps   # rays traced by k_extend launches (k_tail's excluded)
         launches_per_step = max(1, n_ext // args.steps)
         avg_launch_ms = ms_extend / max(1, n_ext)
-        bytes_per_launch = bytes_per_ray * rays_rank0_per_step / launches_per_step
-        achieved_gbs = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
-        valu_tflops = flops_per_ray * rays_rank0_per_step / launches_per_step / (avg_launch_ms * 1e-3) / 1e12 if avg_launch_ms > 0 else 0.0
+        extend_s_per_step = ms_extend / args.steps * 1e-3
+        algorithmic_gbs = bytes_per_ray * rays_rank0_per_step / extend_s_per_step / 1e9 if extend_s_per_step > 0 else 0.0
+        valu_tflops = flops_per_ray * rays_rank0_per_step / extend_s_per_step / 1e12 if extend_s_per_step > 0 else 0.0
+        pmc = pmc_record(args.workload, world, args.bvh)
+        roof = {"bound": "valu_issue", "kernel": "k_extend", "achieved": None, "peak": VALU_PEAK_TLANEOPS, "unit": "Tlane-op/s", "frac": None,
+                "traffic": None, "avg_launch_ms": avg_launch_ms, "launches_per_step": launches_per_step,
+                "extend_ms_per_step": extend_s_per_step * 1e3, "extend_share_of_step": (ms_extend / args.steps) / (dt / args.steps * 1e3),
+                "rays_in_kernel_per_step": rays_rank0_per_step,
+                "algorithmic_gbs": algorithmic_gbs, "algorithmic_hbm_frac": algorithmic_gbs / HBM_PEAK_GBS, "bytes_per_ray": bytes_per_ray,
+                "nodes_per_ray": nodes_per_ray, "prim_tests_per_ray": leaves_per_ray,
+                "valu_tflops": valu_tflops, "valu_flop_frac": valu_tflops / VALU_PEAK_TFLOPS,
+                "note": "bound = VALU issue: frac = active-lane VALU operations per second / (1024 SIMDs x 32 lanes per clock x 2.4 GHz = fp32 vector "
+                        "peak 157.3 TFLOP/s / 2); lane operations per frame from the committed PMC pass (SQ_THREAD_CYCLES_VALU), time live from "
+                        "HIP events.  frac_4cycle_slots is the same product priced at one wave64 instruction per 4 cycles per SIMD with the "
+                        "clock the PMC pass measured (VALU instruction rate x active lanes / 64).  algorithmic_gbs = SURVEY 8(d) bytes / "
+                        "k_extend time: the scene is L1/L2/LDS resident, so that figure is not a roof that binds (hbm_counter_frac is)."}
+        if pmc:
+            ke = pmc["k_extend"]
+            # per k_extend launch, like `achieved`: counters of the launches that did work / launches per frame
+            n_l = max(1, pmc.get("extend_launches_per_frame", launches_per_step))
+            lane_ops_per_s = ke["lane_ops_sum"] / extend_s_per_step if extend_s_per_step > 0 else 0.0
+            roof.update({"achieved": lane_ops_per_s / 1e12, "frac": lane_ops_per_s / 1e12 / VALU_PEAK_TLANEOPS,
+                         "traffic": ke["hbm_bytes_sum"] / n_l,
+                         "frac_4cycle_slots": ke["useful_lane_slots_4cyc"], "valu_inst_rate_4cycle": ke["valu_inst_rate"],
+                         "lanes_active_of_64": ke["lanes_active"],
+                         "hbm_counter_gbs": ke["hbm_bytes_sum"] / extend_s_per_step / 1e9, "hbm_counter_frac": ke["hbm_bytes_sum"] / extend_s_per_step / 1e9 / HBM_PEAK_GBS,
+                         "l2_read_gbs": ke["l2_read_bytes_sum"] / extend_s_per_step / 1e9, "l2_read_frac": ke["l2_read_bytes_sum"] / extend_s_per_step / 1e9 / L2_PEAK_GBS,
+                         "l2_hit": ke["l2_hit"], "l1_hit": ke["l1_hit"], "pmc_clock_ghz": ke.get("eff_clock_ghz"),
+                         "pmc": {"source": pmc["source"], "k_extend_by_level": ke["by_level"],
+                                 "k_shade": {k: v for k, v in (pmc.get("k_shade") or {}).items() if k != "by_level"},
+                                 "k_tail": {k: v for k, v in (pmc.get("k_tail") or {}).items() if k != "by_level"}}})
+        else:
+            roof["pmc"] = {"source": None, "note": f"no PMC pass on file for workload {args.workload} / bvh {args.bvh} / {world} rank(s): run profiles/tools/collect.sh"}
         out = {
             "metric": "Mrays/s (whole node), bunny-class scene 1080p",
             "value": rays_all / dt_max / 1e6,
@@ -203,22 +272,26 @@ def main():
             "config": {"workload": args.workload, "image": [w, h], "samples_per_dim": samples, "depth": depth,
                        "primitives": scene.n_prims,
                        "bvh": ("device " + (os.environ.get("MI_TRACER_BUILDER") or "ploc").upper()) if build else "host binned SAH", "bvh_depth": build.depth if build else scene.bvh_depth,
-                       "bvh_sah_cost": sah_cost, "bvh_build_ms": build.ms_build if build else None, "sharding": f"tile32x{world}",
+                       "bvh_sah_cost": sah_cost, "bvh_build_ms": build.ms_build if build else None,
+                       "sharding": f"image tiles 32x32, tile k -> rank k % {world}, BVH replicated; sample-range sharding + sum-reduce not built "
+                                   "(a reduce over ranks would round differently from the reference's per-pixel sample order)",
                        "exchange": None if world == 1 else ("RCCL gather of RGBA8 tiles to rank 0" if args.backend == "nccl" else "REHEARSAL: gloo, all ranks on one GPU"),
                        "rays_per_step": rays_all / args.steps},
-            "roofline": {"bound": "hbm", "kernel": "k_extend", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": pmc_traffic(args.workload, world),
-                         "bytes_per_ray": bytes_per_ray, "nodes_per_ray": nodes_per_ray, "prim_tests_per_ray": leaves_per_ray,
-                         "avg_launch_ms": avg_launch_ms, "launches_per_step": launches_per_step,
-                         "valu_tflops": valu_tflops, "valu_frac": valu_tflops / VALU_PEAK_TFLOPS,
-                         "extend_share_of_step": (ms_extend / args.steps) / (dt / args.steps * 1e3),
-                         "rays_in_kernel_per_step": rays_rank0_per_step,
-                         "pmc": pmc_record(args.workload, world),
-                         "note": "achieved = algorithmic bytes (64 B per quantised 4-wide node visit, 64 B per primitive test, 128 B ray-stream traffic "
-                                 "per ray, counted on the GPU's own traversal) / k_extend time; the ~10 MB scene is L2/MALL "
-                                 "resident, so most of these bytes never reach HBM (see traffic) and frac can exceed 1: the "
-                                 "kernel is VALU-issue/latency bound, not HBM bound (DESIGN.md section 3)"},
+            "roofline": roof,
         }
+        if phases:
+            out["phases"] = phases
+        if world == 1:
+            # the Tracer boundary hands back HOST bytes (HipTracer::traceImage -> mi_render): the same frame with the RGB8 copy to a
+            # pageable host buffer, PCIe-inclusive; never `value`
+            pf = P.Context.params(w, h, samples, depth, seed=0)
+            ctx.render(pf, want_mean=False)
+            t1 = time.perf_counter()
+            rh = 0
+            for _ in range(max(2, args.steps // 2)):
+                rh += ctx.render(pf, want_mean=False)[2].rays_cast
+            out["value_host_output"] = {"value": rh / (time.perf_counter() - t1) / 1e6, "unit": "Mrays/s",
+                                        "what": "mi_render with the RGB8 frame copied to a pageable host buffer (what HipTracer::traceImage calls), PCIe-inclusive"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"], band = cpu_baseline(scene, w, h, samples, depth, args.cpu_seconds)
             # second half of the metric ("RMSE vs CpuTracer"): the rows the oracle has just rendered against the
@@ -241,28 +314,16 @@ def main():
         dist.destroy_process_group()
 
 
-def pmc_record(workload, world):
-    """L2 / L1 hit rates, VALU busy fraction and active lanes per VALU instruction of k_extend by level, from the
-    PMC passes committed under profiles/ (None if this workload was not profiled)."""
-    path = os.path.join(ROOT, "profiles", "traffic.json")
-    if world != 1 or not os.path.exists(path):
+def pmc_record(workload, world, bvh):
+    """Counter-derived figures of the render kernels for this workload from the PMC passes committed under profiles/
+    (profiles/roofline_pmc.json, written by profiles/tools/pmc_to_json.py from raw rocprofv3 --pmc output; host-built
+    tree, one GPU).  None if this configuration was not profiled."""
+    path = os.path.join(ROOT, "profiles", "roofline_pmc.json")
+    if world != 1 or bvh != "host" or not os.path.exists(path):
         return None
     with open(path) as f:
         rec = json.load(f).get(workload)
-    return {k: v for k, v in rec.items() if k.endswith("levels_0_1_2") or k == "counters_note"} if rec else None
-
-
-def pmc_traffic(workload, world):
-    """HBM bytes per k_extend launch from the PMC passes committed under profiles/
-    (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of this same command;
-    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  None if no
-    measurement of this workload is on file."""
-    path = os.path.join(ROOT, "profiles", "traffic.json")
-    if world != 1 or not os.path.exists(path):
-        return None
-    with open(path) as f:
-        rec = json.load(f).get(workload)
-    return rec["hbm_bytes_per_launch"] if rec else None
+    return rec if rec and rec.get("k_extend") else None
 
 
 def cpu_baseline(scene, w, h, samples, depth, budget_s):
@@ -270,7 +331,17 @@ def cpu_baseline(scene, w, h, samples, depth, budget_s):
     this host's cores over a bounded band of rows of the same workload."""
     import pathtracer_amd as P
     from oracle import oracle_py as O
-    cores = min(16, len(os.sched_getaffinity(0)))
+    # threads = hardware_concurrency() in the reference (src/main.cu:5).  On the GPU box the visible CPUs are the whole
+    # machine's while a one-GPU job's share is OMP_NUM_THREADS (16) of them: that many threads are used, both are stated.
+    nproc = len(os.sched_getaffinity(0))
+    share = int(os.environ.get("OMP_NUM_THREADS", "0") or 0)
+    cores = max(1, min(nproc, share) if share > 0 else nproc)
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "unknown")
+    except OSError:
+        pass
     rows = 2
     mid = h // 2
     p = P.Context.params(w, h, samples, depth, seed=0)
@@ -281,7 +352,7 @@ def cpu_baseline(scene, w, h, samples, depth, budget_s):
     y0 = max(0, mid - rows // 2)
     y1 = min(h, y0 + rows)
     omean, orgb, c = O.render(scene, p, threads=cores, rows=(y0, y1))
-    return {"value": c.rays / (c.ms * 1e-3) / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+    return {"value": c.rays / (c.ms * 1e-3) / 1e6, "unit": "Mrays/s", "cores": cores, "host_nproc": nproc, "cpu_model": model, "kind": "port",
             "sample": f"rows [{y0},{min(h, y0 + rows)}) of the same {w}x{h} workload, {c.rays} rays in {c.ms / 1e3:.1f} s",
             "nodes_per_ray": c.node_visits / max(1, c.rays), "prim_tests_per_ray": c.leaf_tests / max(1, c.rays)}, (y0, y1, omean, orgb)
 

@@ -1,0 +1,29 @@
+# usage (on the GPU box, from the repo root):  bash profiles/tools/collect.sh <tag> [workload]
+# Raw rocprofv3 output goes to gpurun_out/<tag>/; profiles/tools/pmc_to_json.py turns it into the JSON bench.py reads.
+# Passes (each its own run, counters never combined with a trace):
+#   stats : --kernel-trace --stats of `bench.py --steps 10 --warmup 3 --no-cpu-baseline`  (durations)
+#   fetch / write : HBM-side bytes (FETCH_SIZE, WRITE_SIZE)          of ONE frame (profiles/tools/one_frame.py)
+#   sq    : VALU issue and lane counters, wave cycles                 "
+#   tcc / tcp : L2 and vector-L1 requests                             "
+#   grbm  : GRBM_GUI_ACTIVE (effective clock)                          "
+set -e
+TAG=$1
+WL=${2:-C3-blob82k-1080p-16spp}
+R=${GRAFT_REPO_ROOT:-$PWD}
+OUT=$R/gpurun_out/$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/stats -o run --output-format csv -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --workload $WL > $OUT/bench_profiled.json 2> $OUT/stats.log
+pass() { # name, counters...
+    n=$1; shift
+    timeout -s KILL 180 rocprofv3 --pmc "$@" -d $OUT/$n -o run --output-format csv -- python $R/profiles/tools/one_frame.py $WL > $OUT/$n.out 2> $OUT/$n.log
+}
+pass fetch FETCH_SIZE
+pass write WRITE_SIZE
+pass sq SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY
+pass sq2 SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_FLAT SQ_ACTIVE_INST_ANY || true
+pass tcc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
+pass tcp TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum
+pass grbm GRBM_GUI_ACTIVE || true
+cd $R
+python profiles/tools/pmc_to_json.py $OUT $TAG $WL
