@@ -126,9 +126,23 @@ __device__ __forceinline__ void sincos_poly(float p, float &s_out, float &c_out)
 }
 
 // ------------------------------------------------------------ shard geometry
+// Division by a launch-invariant divisor d >= 1 in four VALU instructions: q = (t + ((n - t) >> s1)) >> s2 with
+// t = mulhi(m, n).  d a power of two: m = 0, s1 = 0, s2 = log2 d.  Otherwise the 33-bit magic number of
+// Granlund & Montgomery in its add-and-shift form: m = floor(2^(33+L) / d) - 2^32 + 1, s1 = 1, s2 = L = floor(log2 d).
+// (hipcc expands a 32-bit division by a run-time value into ~30 instructions; the slot -> pixel mapping below has
+// seven of them and runs for every ray in k_shade: 40 % of that kernel's VALU instructions.)  The host builds
+// and checks the constants (fastdiv_make in mi_tracer.hip).
+struct FastDiv {
+    uint32_t m, s1, s2;
+};
+__device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv &d) {
+    const uint32_t t = __umulhi(d.m, n);
+    return (t + ((n - t) >> d.s1)) >> d.s2;
+}
 struct ShardGeom {
     int32_t width, height, tile_w, tile_h, tiles_x, n_tiles, rank, count;
     int32_t samples; // per dimension
+    FastDiv d_tpix, d_tiles_x, d_tile_w, d_sbw, d_samples; // by tile_w * tile_h, tiles_x, tile_w, tile_w / 8 (or 1), samples
 };
 // Local pixel q (tile-major, row-major inside the tile; the order documented for
 // mi_render_device) -> image pixel.  Returns false for pixels of edge tiles that
@@ -136,11 +150,11 @@ struct ShardGeom {
 // pixel count does not fit (64-bit integer division is ~100 instructions on gfx950).
 __device__ __forceinline__ bool local_to_pixel(const ShardGeom &g, uint32_t q, int &px, int &py) {
     uint32_t tpix = (uint32_t)(g.tile_w * g.tile_h);
-    uint32_t j = q / tpix;
+    uint32_t j = fdiv(q, g.d_tpix);
     uint32_t off = q - j * tpix;
     uint32_t gt = (uint32_t)g.rank + j * (uint32_t)g.count;
-    uint32_t ty = gt / (uint32_t)g.tiles_x, tx = gt - ty * (uint32_t)g.tiles_x;
-    uint32_t oy = off / (uint32_t)g.tile_w, ox = off - oy * (uint32_t)g.tile_w;
+    uint32_t ty = fdiv(gt, g.d_tiles_x), tx = gt - ty * (uint32_t)g.tiles_x;
+    uint32_t oy = fdiv(off, g.d_tile_w), ox = off - oy * (uint32_t)g.tile_w;
     px = (int)(tx * (uint32_t)g.tile_w + ox);
     py = (int)(ty * (uint32_t)g.tile_h + oy);
     return gt < (uint32_t)g.n_tiles && px < g.width && py < g.height;
@@ -151,11 +165,11 @@ __device__ __forceinline__ bool local_to_pixel(const ShardGeom &g, uint32_t q, i
 __device__ __forceinline__ uint32_t slot_to_local(const ShardGeom &g, uint32_t lp) {
     if ((g.tile_w & 7) || (g.tile_h & 7)) return lp;
     uint32_t tpix = (uint32_t)(g.tile_w * g.tile_h);
-    uint32_t j = lp / tpix;
+    uint32_t j = fdiv(lp, g.d_tpix);
     uint32_t off = lp - j * tpix;
     uint32_t sub = off >> 6, in = off & 63u;
     uint32_t sbw = (uint32_t)g.tile_w >> 3;
-    uint32_t sby = sub / sbw, sbx = sub - sby * sbw;
+    uint32_t sby = fdiv(sub, g.d_sbw), sbx = sub - sby * sbw;
     uint32_t x = sbx * 8u + (in & 7u), y = sby * 8u + (in >> 3);
     return j * tpix + y * (uint32_t)g.tile_w + x;
 }
@@ -266,12 +280,12 @@ __device__ __forceinline__ void stream_chunk(const uint32_t *cnt, uint32_t fixed
 // generate kernel and no stored primary ray: level 0 of k_extend and of k_shade both
 // call this (camera.cu:6-16 is ~30 instructions; a stored ray is 32 B written + 64 B
 // read).  Returns false for slots of edge tiles that fall outside the image.
-__device__ __forceinline__ bool primary_ray(const DevScene &sc, const ShardGeom &g, uint32_t pix0, uint32_t npix, uint32_t slot,
+__device__ __forceinline__ bool primary_ray(const DevScene &sc, const ShardGeom &g, uint32_t pix0, uint32_t npix, const FastDiv &d_npix, uint32_t slot,
                                             f3 &o, f3 &dir, int &px, int &py, uint32_t &samp) {
-    samp = slot / npix;
+    samp = fdiv(slot, d_npix);
     uint32_t lp = slot - samp * npix;
     if (!local_to_pixel(g, slot_to_local(g, pix0 + lp), px, py)) return false;
-    int sx = (int)(samp / (uint32_t)g.samples), sy = (int)samp - sx * g.samples;
+    int sx = (int)fdiv(samp, g.d_samples), sy = (int)samp - sx * g.samples;
     // CpuTracer.cu:103-105
     float xx = float(px) - 0.5f + (1 + 2 * sx) / (2.0f * g.samples);
     float yy = float(py) - 0.5f + (1 + 2 * sy) / (2.0f * g.samples);
@@ -305,8 +319,12 @@ k_generate_primary(DevScene sc, int width, int height, int samples, int64_t firs
 }
 
 // ------------------------------------------------------------------- extend
+// Running closest hit of a ray: 8 B.  The barycentrics of trimesh.cu:102-103 are needed only where a mesh has
+// per-vertex materials (trimesh.cu:110-116); hit_surface recomputes them there from (o, d, t) with the
+// arithmetic of tri_test — the same bits — so they cost neither two registers in every traversal lane nor
+// 16 of the 32 B a hit record used to take in the stream.
 struct Hit {
-    float t, u, v;
+    float t;
     int slot;
 };
 
@@ -337,7 +355,7 @@ __device__ __forceinline__ void tri_test(const DevScene &sc, int slot, f3 o, f3 
     float v = dot3(xyz(vi), hit);
     bool ok = ((pz < 0) != (dz < 0)) && !(t > h.t) && !(u < 0 || u > 1 || v < 0 || v > 1 || u + v > 1);
     if (ok && t == h.t) ok = tie_allows(sc, h.slot, slot, true);
-    if (ok) { h.t = t; h.u = u; h.v = v; h.slot = slot; }
+    if (ok) { h.t = t; h.slot = slot; }
 }
 
 __device__ __forceinline__ void sphere_test(const DevScene &sc, int slot, f3 o, f3 d, Hit &h) { // sphere.cu:5-35
@@ -355,7 +373,7 @@ __device__ __forceinline__ void sphere_test(const DevScene &sc, int slot, f3 o, 
     if (t1 > MI_EPS && (t1 < h.t || (t1 == h.t && tie_allows(sc, h.slot, slot, false)))) t = t1;
     else if (t2 < h.t || (t2 == h.t && tie_allows(sc, h.slot, slot, false))) t = t2;
     else return;
-    h.t = t; h.u = 0.0f; h.v = 0.0f; h.slot = slot;
+    h.t = t; h.slot = slot;
 }
 
 __device__ __forceinline__ void prim_test(const DevScene &sc, int slot, f3 o, f3 d, Hit &h) { // geometry.h:26-29
@@ -433,7 +451,7 @@ __device__ __forceinline__ void lane_start(const DevScene &sc, Lane &L, f3 o, f3
     L.seln[0] = inv.x < 0.0f ? MI_Q_SEL_HI : MI_Q_SEL_LO;
     L.seln[1] = inv.y < 0.0f ? MI_Q_SEL_HI : MI_Q_SEL_LO;
     L.seln[2] = inv.z < 0.0f ? MI_Q_SEL_HI : MI_Q_SEL_LO;
-    L.h = Hit{t0, 0.0f, 0.0f, -1};
+    L.h = Hit{t0, -1};
     L.sp = 0;
     // bvh.cu:174-176,180-183: nothing to hit / a single primitive / a tree
     L.cur = sc.n_tri + sc.n_sph == 0 ? MI_DONE : sc.root_ref;
@@ -552,8 +570,8 @@ __device__ __forceinline__ void leaf_phase(const DevScene &sc, Lane &L, lds_int 
 template <bool COUNT, bool PRIMARY, bool ANY = false>
 __global__ void __launch_bounds__(MI_BLOCK, 6)
 k_extend(DevScene sc, const uint32_t *count_ptr, uint32_t fixed_count, uint32_t segcap,
-         const float4 *ray_o, const float4 *ray_d, float4 *hits, int *ovf, unsigned long long *work_stats, int refill_min,
-         int leaf_min, ShardGeom g, uint32_t pix0, uint32_t npix, uint32_t *primary_count,
+         const float4 *ray_o, const float4 *ray_d, float2 *hits, int *ovf, unsigned long long *work_stats, int refill_min,
+         int leaf_min, ShardGeom g, uint32_t pix0, uint32_t npix, FastDiv d_npix, uint32_t *primary_count,
          const uint32_t *tail_level, int level, uint32_t deal_rot) {
     __shared__ int lds_stack[MI_LDS_STACK * MI_BLOCK];
     if (!PRIMARY && tail_level && tail_took_over(tail_level, level)) return;
@@ -586,7 +604,7 @@ k_extend(DevScene sc, const uint32_t *count_ptr, uint32_t fixed_count, uint32_t 
     uint32_t slot = 0;
     Lane L;
     L.cur = MI_DONE; L.sp = 0;
-    L.h = Hit{MI_NO_HIT, 0.0f, 0.0f, -1};
+    L.h = Hit{MI_NO_HIT, -1};
     L.o = L.d = L.ia = L.ic = mk3(0, 0, 0);
     L.seln[0] = L.seln[1] = L.seln[2] = MI_Q_SEL_LO;
     unsigned long long act = 0ull; // ballot of `active`
@@ -616,7 +634,7 @@ k_extend(DevScene sc, const uint32_t *count_ptr, uint32_t fixed_count, uint32_t 
                     int px, py;
                     uint32_t samp;
                     const bool real = rng_next + (uint32_t)lane < rng_end &&
-                                      primary_ray(sc, g, pix0, npix, rng_next + (uint32_t)lane, co, cd, px, py, samp);
+                                      primary_ray(sc, g, pix0, npix, d_npix, rng_next + (uint32_t)lane, co, cd, px, py, samp);
                     chunk_valid = __ballot(real);
                     n_primary += (uint32_t)__popcll(chunk_valid);
                     lds_dir[threadIdx.x] = cd.x;
@@ -692,7 +710,7 @@ k_extend(DevScene sc, const uint32_t *count_ptr, uint32_t fixed_count, uint32_t 
             node_phase(sc, L, stack, my_ovf, ovf_stride, lds_treelet);
         }
         if (active && L.cur == MI_DONE) {
-            hits[slot] = make_float4(L.h.t, __int_as_float(L.h.slot), L.h.u, L.h.v);
+            hits[slot] = make_float2(L.h.t, __int_as_float(L.h.slot));
             active = false;
             if (COUNT) { max_ray_steps = max(max_ray_steps, ray_steps); ray_steps = 0; }
         }
@@ -719,7 +737,7 @@ __device__ __forceinline__ DMat load_mat(const DevScene &sc, uint32_t id) {
 }
 
 // Geometric normal and material at a hit (trimesh.cu:107-119, sphere.cu:23-32).
-__device__ __forceinline__ void hit_surface(const DevScene &sc, int slot, float t, float u, float v, f3 o, f3 d, f3 &N, DMat &m) {
+__device__ __forceinline__ void hit_surface(const DevScene &sc, int slot, float t, f3 o, f3 d, f3 &N, DMat &m) {
     if ((uint32_t)slot >= sc.n_tri) {
         int k = slot - (int)sc.n_tri;
         float4 cr = sc.sph[k];
@@ -729,6 +747,11 @@ __device__ __forceinline__ void hit_surface(const DevScene &sc, int slot, float 
         N = xyz(sc.tri_normal[slot]);
         const uint32_t *mid = sc.tri_mat + 3 * (size_t)slot;
         if (sc.tri_has_vmat[slot]) { // trimesh.cu:110-116 with material.h:91-100,137-146
+            // u, v of trimesh.cu:98-101 again, from the accepted t: the operations of tri_test on the same inputs
+            const char *rec = (const char *)sc.tri + ((uint32_t)slot << 6);
+            const float4 v0 = *(const float4 *)(rec), ui = *(const float4 *)(rec + 16), vi = *(const float4 *)(rec + 32);
+            const f3 hit = (o - xyz(v0)) + t * d;
+            const float u = dot3(xyz(ui), hit), v = dot3(xyz(vi), hit);
             float w = 1 - u - v;     // trimesh.cu:102
             // (a*w + b*u) + c*v, accumulated one vertex material at a time (same
             // association, a third of the registers of loading all three first)
@@ -835,7 +858,7 @@ __device__ __forceinline__ uint64_t path_id(const ShardGeom &g, int px, int py, 
 // or (e, w) of this level are stored and the continuation ray (no, nd) with throughput
 // Tn is returned with true.
 __device__ __forceinline__ bool shade_path(const DevScene &sc, uint64_t seed, uint64_t path, int level, int depth_left, uint32_t slot,
-                                           f3 o, f3 d, float4 T, float t, int pslot, float hu, float hv, float4 *hist,
+                                           f3 o, f3 d, float4 T, float t, int pslot, float4 *hist,
                                            size_t cap, size_t e_off, uint32_t &emask, float4 *path_out, f3 &no, f3 &nd, float4 &Tn) {
     if (pslot < 0) { // CpuTracer.cu:124-125: miss -> cubemap colour, or (1,1,1,1) without a cubemap
         const float4 bg = sc.cube ? cubemap_color(sc.cube, d) : make_float4(1.0f, 1.0f, 1.0f, 1.0f);
@@ -844,7 +867,7 @@ __device__ __forceinline__ bool shade_path(const DevScene &sc, uint64_t seed, ui
     }
     f3 N;
     DMat m;
-    hit_surface(sc, pslot, t, hu, hv, o, d, N, m);
+    hit_surface(sc, pslot, t, o, d, N, m);
     float4 e = mul4(m.ke, 32.0f); // CpuTracer.cu:131,185
     if (depth_left < 0) {         // CpuTracer.cu:130-131
         path_out[slot] = clamp01_4(fold_history(hist, cap, e_off, slot, level, emask, e));
@@ -905,8 +928,8 @@ __device__ __forceinline__ bool shade_path(const DevScene &sc, uint64_t seed, ui
 // are appended to the next level's stream `out`.
 template <bool PRIMARY>
 __global__ void __launch_bounds__(MI_BLOCK)
-k_shade(DevScene sc, ShardGeom g, uint32_t pix0, uint32_t npix, int level, int depth_left, uint64_t seed, RayStream in,
-        const uint32_t *count_ptr, const float4 *hits, float4 *hist, size_t cap, size_t e_off, float4 *path_out, RayStream out,
+k_shade(DevScene sc, ShardGeom g, uint32_t pix0, uint32_t npix, FastDiv d_npix, int level, int depth_left, uint64_t seed, RayStream in,
+        const uint32_t *count_ptr, const float2 *hits, float4 *hist, size_t cap, size_t e_off, float4 *path_out, RayStream out,
         uint32_t *next_count, uint32_t n_fixed, const uint32_t *tail_level) {
     if (!PRIMARY && tail_took_over(tail_level, level)) return;
     // i runs over the virtual positions (64 per virtual chunk) of the input stream
@@ -919,11 +942,12 @@ k_shade(DevScene sc, ShardGeom g, uint32_t pix0, uint32_t npix, int level, int d
     // The stream records of the NEXT iteration are fetched before this iteration's are used
     // (software pipelining): the kernel is bound by memory latency x resident waves, and this
     // doubles what each wave has in flight on its longest (HBM) leg.
-    struct In { bool live; uint32_t pos; float4 o4, d4, T, h4; };
+    struct In { bool live; uint32_t pos; float4 o4, d4, T; float2 h2; };
     auto fetch = [&](uint32_t i) {
         In r;
         r.live = false; r.pos = 0;
-        r.o4 = r.d4 = r.h4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        r.o4 = r.d4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        r.h2 = make_float2(0.0f, 0.0f);
         r.T = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
         if (i < n_virtual) {
             uint32_t first, end;
@@ -932,8 +956,13 @@ k_shade(DevScene sc, ShardGeom g, uint32_t pix0, uint32_t npix, int level, int d
             r.live = r.pos < end;
         }
         if (r.live) {
-            if (!PRIMARY) { r.o4 = in.o[r.pos]; r.d4 = in.d[r.pos]; r.T = in.thr[r.pos]; }
-            r.h4 = hits[r.pos];
+            if (!PRIMARY) {
+                r.o4 = in.o[r.pos];
+                r.d4 = in.d[r.pos];
+                // level 0 stores no throughput: T_1 = w_0 * (1,1,1,1) = w_0 bit for bit, which the history holds already
+                r.T = level == 1 ? hist[(uint32_t)__float_as_int(r.o4.w)] : in.thr[r.pos];
+            }
+            r.h2 = hits[r.pos];
         }
         return r;
     };
@@ -953,13 +982,13 @@ k_shade(DevScene sc, ShardGeom g, uint32_t pix0, uint32_t npix, int level, int d
         if (live) {
             if (PRIMARY) {
                 slot = pos_in;
-                live = primary_ray(sc, g, pix0, npix, slot, o, d, px, py, samp);
+                live = primary_ray(sc, g, pix0, npix, d_npix, slot, o, d, px, py, samp);
                 if (!live) path_out[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             } else {
                 slot = (uint32_t)__float_as_int(cur.o4.w);
                 o = xyz(cur.o4);
                 d = xyz(cur.d4);
-                samp = slot / npix;
+                samp = fdiv(slot, d_npix);
                 uint32_t lp = slot - samp * npix;
                 local_to_pixel(g, slot_to_local(g, pix0 + lp), px, py);
             }
@@ -968,15 +997,14 @@ k_shade(DevScene sc, ShardGeom g, uint32_t pix0, uint32_t npix, int level, int d
         float4 Tn = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         uint32_t emask = PRIMARY ? 0u : __float_as_uint(cur.d4.w); // which earlier levels stored an emission term
         if (live) {
-            const float4 h4 = cur.h4;
-            alive = shade_path(sc, seed, path_id(g, px, py, samp), level, depth_left, slot, o, d, T, h4.x, __float_as_int(h4.y), h4.z, h4.w,
+            alive = shade_path(sc, seed, path_id(g, px, py, samp), level, depth_left, slot, o, d, T, cur.h2.x, __float_as_int(cur.h2.y),
                                hist, cap, e_off, emask, path_out, no, nd, Tn);
         }
         const uint32_t pos = out_base + queue_reserve(alive, my_count);
         if (alive) {
             out.o[pos] = make_float4(no.x, no.y, no.z, __int_as_float((int)slot));
             out.d[pos] = make_float4(nd.x, nd.y, nd.z, __uint_as_float(emask));
-            out.thr[pos] = Tn;
+            if (!PRIMARY) out.thr[pos] = Tn; // level 1 reads w_0 from the history instead (above)
         }
     }
 }
@@ -991,7 +1019,7 @@ k_shade(DevScene sc, ShardGeom g, uint32_t pix0, uint32_t npix, int level, int d
 // then publishes its level in *tail_level so the per-level kernels behind it return
 // immediately.  Rays traced beyond the first level are added to *extra_rays.
 __global__ void __launch_bounds__(MI_BLOCK, 5)
-k_tail(DevScene sc, ShardGeom g, uint32_t pix0, uint32_t npix, int level0, int depth_total, uint64_t seed, RayStream in,
+k_tail(DevScene sc, ShardGeom g, uint32_t pix0, uint32_t npix, FastDiv d_npix, int level0, int depth_total, uint64_t seed, RayStream in,
        const uint32_t *count_ptr, uint32_t threshold, uint32_t *tail_level, float4 *hist, size_t cap, size_t e_off, float4 *path_out, int *ovf,
        unsigned long long *extra_rays, int shade_min, int refill_min) {
     __shared__ int lds_stack[MI_LDS_STACK * MI_BLOCK];
@@ -1021,7 +1049,7 @@ k_tail(DevScene sc, ShardGeom g, uint32_t pix0, uint32_t npix, int level0, int d
     float4 T = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     Lane L;
     L.cur = MI_DONE; L.sp = 0;
-    L.h = Hit{MI_NO_HIT, 0.0f, 0.0f, -1};
+    L.h = Hit{MI_NO_HIT, -1};
     L.o = L.d = L.ia = L.ic = mk3(0, 0, 0);
     L.seln[0] = L.seln[1] = L.seln[2] = MI_Q_SEL_LO;
     unsigned long long act = 0ull;
@@ -1042,7 +1070,7 @@ k_tail(DevScene sc, ShardGeom g, uint32_t pix0, uint32_t npix, int level0, int d
                 if (!active && rank < avail) {
                     const float4 o4 = in.o[rng_next + rank];
                     slot = (uint32_t)__float_as_int(o4.w);
-                    T = in.thr[rng_next + rank];
+                    T = level0 == 1 ? hist[slot] : in.thr[rng_next + rank]; // level 0 stores no throughput (k_shade)
                     level = level0;
                     const float4 d4 = in.d[rng_next + rank];
                     emask = __float_as_uint(d4.w);
@@ -1060,14 +1088,14 @@ k_tail(DevScene sc, ShardGeom g, uint32_t pix0, uint32_t npix, int level0, int d
         if (ns > 0 && (ns >= shade_min || (nl == 0 && nn == 0))) {
             bool cont = false;
             if (want_shade) {
-                uint32_t samp = slot / npix;
+                uint32_t samp = fdiv(slot, d_npix);
                 uint32_t lp = slot - samp * npix;
                 int px, py;
                 local_to_pixel(g, slot_to_local(g, pix0 + lp), px, py);
                 f3 no, nd;
                 float4 Tn;
-                cont = shade_path(sc, seed, path_id(g, px, py, samp), level, depth_total - level, slot, L.o, L.d, T, L.h.t, L.h.slot, L.h.u,
-                                  L.h.v, hist, cap, e_off, emask, path_out, no, nd, Tn);
+                cont = shade_path(sc, seed, path_id(g, px, py, samp), level, depth_total - level, slot, L.o, L.d, T, L.h.t, L.h.slot,
+                                  hist, cap, e_off, emask, path_out, no, nd, Tn);
                 if (cont) {
                     T = Tn;
                     level++;
@@ -1120,10 +1148,10 @@ k_resolve(ShardGeom g, uint32_t pix0, uint32_t npix, const float4 *path_out, flo
 
 // Probe output for mi_trace_primary / mi_trace_rays.
 __global__ void __launch_bounds__(MI_BLOCK)
-k_probe_out(DevScene sc, int64_t n, const float4 *ray_o, const float4 *ray_d, const float4 *hits, int32_t *prim_id, float *t_out, float *n_out) {
+k_probe_out(DevScene sc, int64_t n, const float4 *ray_o, const float4 *ray_d, const float2 *hits, int32_t *prim_id, float *t_out, float *n_out) {
     int64_t i = (int64_t)blockIdx.x * MI_BLOCK + threadIdx.x;
     if (i >= n) return;
-    float4 h = hits[i];
+    float2 h = hits[i];
     int slot = __float_as_int(h.y);
     prim_id[i] = slot < 0 ? -1 : sc.prim_id[slot];
     t_out[i] = h.x;
@@ -1131,14 +1159,14 @@ k_probe_out(DevScene sc, int64_t n, const float4 *ray_o, const float4 *ray_d, co
         f3 N = mk3(0, 0, 0);
         if (slot >= 0) {
             DMat m;
-            hit_surface(sc, slot, h.x, h.z, h.w, xyz(ray_o[i]), xyz(ray_d[i]), N, m);
+            hit_surface(sc, slot, h.x, xyz(ray_o[i]), xyz(ray_d[i]), N, m);
         }
         n_out[3 * i] = N.x; n_out[3 * i + 1] = N.y; n_out[3 * i + 2] = N.z;
     }
 }
 
 __global__ void __launch_bounds__(MI_BLOCK)
-k_probe_occluded(int64_t n, const float4 *hits, uint8_t *out) {
+k_probe_occluded(int64_t n, const float2 *hits, uint8_t *out) {
     int64_t i = (int64_t)blockIdx.x * MI_BLOCK + threadIdx.x;
     if (i < n) out[i] = __float_as_int(hits[i].y) >= 0 ? 1 : 0;
 }

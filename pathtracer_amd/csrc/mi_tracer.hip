@@ -169,9 +169,10 @@ MI_API mi_status mi_ctx_create(int device_id, mi_ctx **out) {
     int occ_e = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_e, k_extend<false, false, false>, MI_BLOCK, 0) == hipSuccess && occ_e > 0)
         c->extend_wg_per_cu = std::min(c->extend_wg_per_cu, occ_e);
-    c->extend_wg_primary = c->extend_wg_per_cu;
+    c->extend_wg_primary = std::min(c->extend_wg_per_cu, 6); // measured: level 0 of C3 1.77 ms with 6 workgroups per CU, 1.87 with 5 or 7
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_e, k_extend<false, true, false>, MI_BLOCK, 0) == hipSuccess && occ_e > 0)
         c->extend_wg_primary = std::min(c->extend_wg_primary, occ_e);
+    c->extend_wg_primary = env_int("MI_TRACER_EXTEND_WG_PRIMARY", 1, 16, c->extend_wg_primary); // stack_grid() covers whatever is chosen
     // k_tail is persistent and deals its work statically over the grid: launch exactly as many
     // workgroups as are resident at once (a second round would start after the first has finished).
     // Computed after extend_wg_per_cu is final; the overflow stacks are sized for the largest of the
@@ -767,6 +768,36 @@ static uint32_t deal_rotation(uint32_t n_waves, uint32_t npix, int spp) {
     return rot < n_waves ? rot : 0u;
 }
 
+// Constants of fdiv() (mi_kernels.h) for the divisor d >= 1, checked against the machine's division on the edges
+// of the range and on a pseudo-random sample before any kernel uses them.
+static bool fastdiv_make(uint32_t d, FastDiv &out) {
+    if (d == 0) return false;
+    int L = 31;
+    while (!((d >> L) & 1u)) L--;
+    if ((d & (d - 1u)) == 0u) {
+        out = FastDiv{0u, 0u, (uint32_t)L};
+    } else {
+        const unsigned __int128 num = (unsigned __int128)1 << (33 + L);
+        out = FastDiv{(uint32_t)(uint64_t)(num / d - ((unsigned __int128)1 << 32) + 1), 1u, (uint32_t)L};
+    }
+    auto q = [&](uint32_t n) { const uint32_t t = (uint32_t)(((uint64_t)out.m * n) >> 32); return (t + ((n - t) >> out.s1)) >> out.s2; };
+    uint32_t x = 0x9E3779B9u;
+    for (int i = 0; i < 4096; i++) {
+        uint32_t n;
+        switch (i) {
+            case 0: n = 0u; break;
+            case 1: n = d - 1u; break;
+            case 2: n = d; break;
+            case 3: n = 0xFFFFFFFFu; break;
+            case 4: n = 0xFFFFFFFFu / d * d; break;
+            case 5: n = 0xFFFFFFFFu / d * d - 1u; break;
+            default: x = x * 1664525u + 1013904223u; n = (i & 1) ? x : x / d * d + ((i & 2) ? d - 1u : 0u); break; // random, and the two sides of a multiple
+        }
+        if (q(n) != n / d) return false;
+    }
+    return true;
+}
+
 static mi_status make_geom(const mi_render_params *p, ShardGeom &g) {
     if (!p) return fail(MI_ERR_INVALID, "params is NULL");
     if (p->width <= 0 || p->height <= 0 || p->samples_per_dim <= 0 || p->samples_per_dim > 1024)
@@ -775,6 +806,7 @@ static mi_status make_geom(const mi_render_params *p, ShardGeom &g) {
     g.width = p->width; g.height = p->height;
     g.tile_w = p->tile_w > 0 ? p->tile_w : 32;
     g.tile_h = p->tile_h > 0 ? p->tile_h : 32;
+    if (g.tile_w > 32768 || g.tile_h > 32768) return fail(MI_ERR_INVALID, "tile larger than 32768 pixels on a side");
     g.tiles_x = (g.width + g.tile_w - 1) / g.tile_w;
     int tiles_y = (g.height + g.tile_h - 1) / g.tile_h;
     int64_t nt = (int64_t)g.tiles_x * tiles_y;
@@ -784,6 +816,11 @@ static mi_status make_geom(const mi_render_params *p, ShardGeom &g) {
     g.rank = p->shard_count > 1 ? p->shard_rank : 0;
     if (g.rank < 0 || g.rank >= g.count) return fail(MI_ERR_INVALID, "shard_rank %d not in [0,%d)", g.rank, g.count);
     g.samples = p->samples_per_dim;
+    const bool sub8 = !(g.tile_w & 7) && !(g.tile_h & 7); // slot_to_local walks 8x8 sub-blocks only then
+    if (!fastdiv_make((uint32_t)(g.tile_w * g.tile_h), g.d_tpix) || !fastdiv_make((uint32_t)g.tiles_x, g.d_tiles_x) ||
+        !fastdiv_make((uint32_t)g.tile_w, g.d_tile_w) || !fastdiv_make(sub8 ? (uint32_t)g.tile_w >> 3 : 1u, g.d_sbw) ||
+        !fastdiv_make((uint32_t)g.samples, g.d_samples))
+        return fail(MI_ERR_INVALID, "internal: division constants failed their check");
     return MI_OK;
 }
 
@@ -845,7 +882,8 @@ static mi_status plan_batch(const mi_ctx *c, int64_t npix_b, int spp, int depth,
 // Device memory of a batch and the grids of the persistent kernels (the overflow stacks in `ovf` have one
 // column per thread of the largest of them).
 struct PathMem {
-    float4 *ray_o[2], *ray_d[2], *thr[2], *hits, *path_out, *hist;
+    float4 *ray_o[2], *ray_d[2], *thr[2], *path_out, *hist;
+    float2 *hits; // (t, primitive slot) by stream position
     uint32_t *counters;
     int *ovf;
     uint64_t *totals;
@@ -885,20 +923,22 @@ static mi_status render_batches(mi_ctx *c, const mi_render_params *p, const Shar
         const uint32_t np = (uint32_t)std::min<int64_t>(npix_b, local - (int64_t)pix0);
         const int64_t nslots = (int64_t)np * spp;
         const uint32_t rot0 = deal_rotation((uint32_t)m.egrid0 * (MI_BLOCK / 64), np, spp);
+        FastDiv d_np;
+        if (!fastdiv_make(np, d_np)) return fail(MI_ERR_INVALID, "internal: division constants failed their check");
         HIPCHK(hipMemsetAsync(cnt, 0, kCounterWords * 4, st));
         for (int k = 0; k < levels; k++) {
             const RayStream &sin = rs[k & 1], &sout = rs[(k + 1) & 1];
             unsigned long long *ws = count_work ? (unsigned long long *)m.totals + 2 : nullptr;
             if (per_launch) HIPCHK(hipEventRecord(c->ev[evi++], st)); // 4 events per level: tail | extend | shade
             if (k >= 1 && c->tail_threshold > 0 && !count_work)
-                hipLaunchKernelGGL(k_tail, dim3(m.tgrid), dim3(MI_BLOCK), 0, st, c->sc, g, pix0, np, k, p->depth, p->seed, sin, cnt + k * kLevelWords,
+                hipLaunchKernelGGL(k_tail, dim3(m.tgrid), dim3(MI_BLOCK), 0, st, c->sc, g, pix0, np, d_np, k, p->depth, p->seed, sin, cnt + k * kLevelWords,
                                    (uint32_t)c->tail_threshold, tail_level, m.hist, cap, (size_t)hist_levels * cap, m.path_out, m.ovf,
                                    (unsigned long long *)m.totals + 7, c->shade_min, c->tail_refill);
             if (per_launch) HIPCHK(hipEventRecord(c->ev[evi++], st));
 #define MI_EXTEND_ARGS(PRIM)                                                                                                   \
     dim3((PRIM) ? m.egrid0 : m.egrid), dim3(MI_BLOCK), 0, st, c->sc, (PRIM) ? (const uint32_t *)nullptr : cnt + k * kLevelWords,                   \
         (PRIM) ? (uint32_t)nslots : 0u, segcap, sin.o, sin.d, m.hits, m.ovf, ws,                          \
-        (PRIM) ? c->refill_primary : c->refill_min, c->leaf_min, g, pix0, np, cnt, tail_level, k, (PRIM) ? rot0 : 0u
+        (PRIM) ? c->refill_primary : c->refill_min, c->leaf_min, g, pix0, np, d_np, cnt, tail_level, k, (PRIM) ? rot0 : 0u
             if (k == 0) {
                 if (count_work) hipLaunchKernelGGL((k_extend<true, true>), MI_EXTEND_ARGS(true));
                 else hipLaunchKernelGGL((k_extend<false, true>), MI_EXTEND_ARGS(true));
@@ -909,7 +949,7 @@ static mi_status render_batches(mi_ctx *c, const mi_render_params *p, const Shar
 #undef MI_EXTEND_ARGS
             if (per_launch) HIPCHK(hipEventRecord(c->ev[evi++], st));
 #define MI_SHADE_ARGS                                                                                                          \
-    dim3(sgrid), dim3(MI_BLOCK), 0, st, c->sc, g, pix0, np, k, p->depth - k, p->seed, sin, cnt + k * kLevelWords, m.hits,         \
+    dim3(sgrid), dim3(MI_BLOCK), 0, st, c->sc, g, pix0, np, d_np, k, p->depth - k, p->seed, sin, cnt + k * kLevelWords, m.hits,         \
         m.hist, cap, (size_t)hist_levels * cap, m.path_out, sout, cnt + (k + 1) * kLevelWords, (uint32_t)nslots, tail_level
             if (k == 0) hipLaunchKernelGGL(k_shade<true>, MI_SHADE_ARGS);
             else hipLaunchKernelGGL(k_shade<false>, MI_SHADE_ARGS);
@@ -1006,7 +1046,7 @@ MI_API mi_status mi_render_device(mi_ctx *c, const mi_render_params *p, void *d_
         HIPCHK(c->ray_d[i].ensure(bp.stream_cap * 16));
         HIPCHK(c->thr[i].ensure(bp.stream_cap * 16));
     }
-    HIPCHK(c->hits.ensure(bp.stream_cap * 16));
+    HIPCHK(c->hits.ensure(bp.stream_cap * 8));
     HIPCHK(c->path_out.ensure(bp.cap * 16));
     HIPCHK(c->hist.ensure(bp.cap * 32 * bp.hist_levels));
     HIPCHK(c->counters.ensure(kCounterWords * 4));
@@ -1014,7 +1054,7 @@ MI_API mi_status mi_render_device(mi_ctx *c, const mi_render_params *p, void *d_
     HIPCHK(c->totals.ensure(kTotals * 8));
     PathMem m;
     for (int i = 0; i < 2; i++) { m.ray_o[i] = c->ray_o[i].as<float4>(); m.ray_d[i] = c->ray_d[i].as<float4>(); m.thr[i] = c->thr[i].as<float4>(); }
-    m.hits = c->hits.as<float4>(); m.path_out = c->path_out.as<float4>(); m.hist = c->hist.as<float4>();
+    m.hits = c->hits.as<float2>(); m.path_out = c->path_out.as<float4>(); m.hist = c->hist.as<float4>();
     m.counters = c->counters.as<uint32_t>(); m.ovf = c->ovf.as<int>(); m.totals = c->totals.as<uint64_t>();
     m.egrid = extend_grid(c); m.egrid0 = c->n_cu * c->extend_wg_primary; m.tgrid = c->n_cu * c->tail_wg_per_cu;
     return render_batches(c, p, g, bp, m, d_rgba_mean, d_rgba8, st, stats, true, true);
@@ -1052,7 +1092,7 @@ MI_API mi_status mi_render_device_noalloc(mi_ctx *c, const mi_render_params *p, 
     const size_t fixed = off;
     // The rest holds one batch: the largest multiple of 64 pixels that fits (per slot: two ray streams of three
     // float4 records, hits, path value, 32 B of history per level; plan_batch has the exact stream sizes).
-    auto batch_bytes = [&](const BatchPlan &b) { return 7 * up256(b.stream_cap * 16) + up256(b.cap * 16) + up256(b.cap * 32 * (size_t)b.hist_levels); };
+    auto batch_bytes = [&](const BatchPlan &b) { return 6 * up256(b.stream_cap * 16) + up256(b.stream_cap * 8) + up256(b.cap * 16) + up256(b.cap * 32 * (size_t)b.hist_levels); };
     BatchPlan bp;
     int64_t lo = 0, hi = (std::max<int64_t>(local, 1) + 63) / 64; // in units of 64 pixels; lo fits (0 = nothing), find the largest that fits
     while (lo < hi) {
@@ -1075,7 +1115,7 @@ MI_API mi_status mi_render_device_noalloc(mi_ctx *c, const mi_render_params *p, 
         m.ray_d[i] = (float4 *)carve(bp.stream_cap * 16);
         m.thr[i] = (float4 *)carve(bp.stream_cap * 16);
     }
-    m.hits = (float4 *)carve(bp.stream_cap * 16);
+    m.hits = (float2 *)carve(bp.stream_cap * 8);
     m.path_out = (float4 *)carve(bp.cap * 16);
     m.hist = (float4 *)carve(bp.cap * 32 * (size_t)bp.hist_levels);
     if (off > MI_NOALLOC_BYTES) return fail(MI_ERR_INVALID, "mi_render_device_noalloc: internal sizing error (%zu > %zu)", off, (size_t)MI_NOALLOC_BYTES);
@@ -1180,11 +1220,11 @@ MI_API mi_status mi_assemble_rgb8_device(mi_ctx *c, const mi_render_params *p, c
 static mi_status probe_chunk(mi_ctx *c, int64_t n, int32_t *prim_id_out, float *t_out, float *n_out) {
     hipStream_t st = c->stream;
     hipLaunchKernelGGL((k_extend<false, false>), dim3(extend_grid(c)), dim3(MI_BLOCK), 0, st, c->sc,
-                       (const uint32_t *)nullptr, (uint32_t)n, 0u, c->ray_o[0].as<float4>(), c->ray_d[0].as<float4>(), c->hits.as<float4>(),
-                       c->ovf.as<int>(), (unsigned long long *)nullptr, c->refill_min, c->leaf_min, ShardGeom{}, 0u, 1u,
+                       (const uint32_t *)nullptr, (uint32_t)n, 0u, c->ray_o[0].as<float4>(), c->ray_d[0].as<float4>(), c->hits.as<float2>(),
+                       c->ovf.as<int>(), (unsigned long long *)nullptr, c->refill_min, c->leaf_min, ShardGeom{}, 0u, 1u, FastDiv{0u, 0u, 0u},
                        (uint32_t *)nullptr, (const uint32_t *)nullptr, 0, 0u);
     hipLaunchKernelGGL(k_probe_out, dim3((unsigned)((n + MI_BLOCK - 1) / MI_BLOCK)), dim3(MI_BLOCK), 0, st, c->sc, n, c->ray_o[0].as<float4>(),
-                       c->ray_d[0].as<float4>(), c->hits.as<float4>(), c->probe_i.as<int32_t>(), c->probe_t.as<float>(),
+                       c->ray_d[0].as<float4>(), c->hits.as<float2>(), c->probe_i.as<int32_t>(), c->probe_t.as<float>(),
                        n_out ? c->probe_n.as<float>() : nullptr);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(prim_id_out, c->probe_i.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
@@ -1197,7 +1237,7 @@ static mi_status probe_chunk(mi_ctx *c, int64_t n, int32_t *prim_id_out, float *
 static mi_status probe_alloc(mi_ctx *c, size_t chunk) {
     HIPCHK(c->ray_o[0].ensure(chunk * 16));
     HIPCHK(c->ray_d[0].ensure(chunk * 16));
-    HIPCHK(c->hits.ensure(chunk * 16));
+    HIPCHK(c->hits.ensure(chunk * 8));
     HIPCHK(c->probe_i.ensure(chunk * 4));
     HIPCHK(c->probe_t.ensure(chunk * 4));
     HIPCHK(c->probe_n.ensure(chunk * 12));
@@ -1268,10 +1308,10 @@ MI_API mi_status mi_occluded_rays(mi_ctx *c, int64_t total, const float *rays, c
         HIPCHK(hipMemcpyAsync(c->ray_o[0].p, o4.data(), (size_t)n * 16, hipMemcpyHostToDevice, st));
         HIPCHK(hipMemcpyAsync(c->ray_d[0].p, d4.data(), (size_t)n * 16, hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL((k_extend<false, false, true>), dim3(extend_grid(c)), dim3(MI_BLOCK), 0, st, c->sc, (const uint32_t *)nullptr, (uint32_t)n,
-                           0u, c->ray_o[0].as<float4>(), c->ray_d[0].as<float4>(), c->hits.as<float4>(), c->ovf.as<int>(),
-                           (unsigned long long *)nullptr, c->refill_min, c->leaf_min, ShardGeom{}, 0u, 1u, (uint32_t *)nullptr,
+                           0u, c->ray_o[0].as<float4>(), c->ray_d[0].as<float4>(), c->hits.as<float2>(), c->ovf.as<int>(),
+                           (unsigned long long *)nullptr, c->refill_min, c->leaf_min, ShardGeom{}, 0u, 1u, FastDiv{0u, 0u, 0u}, (uint32_t *)nullptr,
                            (const uint32_t *)nullptr, 0, 0u);
-        hipLaunchKernelGGL(k_probe_occluded, dim3((unsigned)((n + MI_BLOCK - 1) / MI_BLOCK)), dim3(MI_BLOCK), 0, st, n, c->hits.as<float4>(),
+        hipLaunchKernelGGL(k_probe_occluded, dim3((unsigned)((n + MI_BLOCK - 1) / MI_BLOCK)), dim3(MI_BLOCK), 0, st, n, c->hits.as<float2>(),
                            c->probe_i.as<uint8_t>());
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(occluded_out + first, c->probe_i.p, (size_t)n, hipMemcpyDeviceToHost, st));
