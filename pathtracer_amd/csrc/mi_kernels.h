@@ -52,13 +52,17 @@ struct DevScene {
     // first from the root, at most MI_TREELET nodes) that every workgroup keeps in LDS.
     int32_t treelet_base, treelet_count;
 };
+#ifndef MI_TREELET
 #define MI_TREELET 69        // nodes (4.4 KB; 138 measured no better): with the 12-KB stack, seven workgroups of k_extend fit the CU's 160 KB of LDS
+#endif
 #define MI_Q_PAD 0           // whole codes a quantised plane is moved outward beyond its rounding
 #define MI_Q_MARGIN 3.814697265625e-06 // 2^-18: what a plane is moved outward (in F) before it is rounded outward
 #define MI_Q_SEL_LO 0x0701000cu // v_perm_b32 selectors {0x3F, code byte 1, code byte 0, 0x00} of the low / high half
 #define MI_Q_SEL_HI 0x0703020cu
 #define MI_Q_SEL_FLIP 0x00020200u
+#ifndef MI_TREELET_LEVELS
 #define MI_TREELET_LEVELS 4  // root + up to four levels below it, breadth first
+#endif
 
 struct f3 {
     float x, y, z;
@@ -503,6 +507,12 @@ __device__ __forceinline__ void node_phase(const DevScene &sc, Lane &L, lds_int 
         const bool hit = slab_fast_q(PX[c], PY[c], PZ[c], L.seln, self, L.ia, L.ic, L.h.t, tmin);
         K[c] = hit ? tmin : __builtin_inff(); // an empty seat's box is inverted on every axis: never hit
     }
+#ifdef MI_DUMMY_VALU
+    { uint32_t dz = (uint32_t)L.sp;
+#pragma unroll
+      for (int q = 0; q < MI_DUMMY_VALU; q++) asm volatile("v_add_u32 %0, %0, %1" : "+v"(dz) : "v"(PX[q & 3]));
+      asm volatile("" :: "v"(dz)); }
+#endif
     // sorting network, descending by entry distance: K[0] farthest ... K[3] nearest
     cswap(K[0] < K[1], K[0], K[1], R[0], R[1]);
     cswap(K[2] < K[3], K[2], K[3], R[2], R[3]);
@@ -926,8 +936,11 @@ __device__ __forceinline__ bool shade_path(const DevScene &sc, uint64_t seed, ui
 // the ray comes from primary_ray(), throughput (1,1,1,1) (traceRay(r, 1, depth),
 // CpuTracer.cu:114); slots that are not pixels get a zero path value.  Continuation rays
 // are appended to the next level's stream `out`.
+#ifndef MI_SHADE_WG
+#define MI_SHADE_WG 6 // workgroups per CU the compiler must leave room for (80 VGPRs): level-1 shade 0.52 -> 0.49 ms against no bound (85 VGPRs); 7 and 8 spill and are slower
+#endif
 template <bool PRIMARY>
-__global__ void __launch_bounds__(MI_BLOCK)
+__global__ void __launch_bounds__(MI_BLOCK, MI_SHADE_WG)
 k_shade(DevScene sc, ShardGeom g, uint32_t pix0, uint32_t npix, FastDiv d_npix, int level, int depth_left, uint64_t seed, RayStream in,
         const uint32_t *count_ptr, const float2 *hits, float4 *hist, size_t cap, size_t e_off, float4 *path_out, RayStream out,
         uint32_t *next_count, uint32_t n_fixed, const uint32_t *tail_level) {

@@ -82,7 +82,10 @@ struct DevBuf {
 struct mi_ctx {
     int device = 0;
     int n_cu = 256;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr, stream2 = nullptr; // stream2: the second of the two streams the batches of a frame alternate between
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int n_streams = 2;          // MI_TRACER_STREAMS: 1 = every batch on the caller's stream
+    int64_t split_min = 0;      // MI_TRACER_SPLIT_MIN: path slots each half must have for a one-batch frame to be cut in two (default 4 x the tail threshold)
     bool has_scene = false;
     DevScene sc{};
     uint32_t n_nodes = 0;   // of the binary tree kept in `nodes` (download, quality); the kernels walk `nodes4`
@@ -90,7 +93,8 @@ struct mi_ctx {
     DevBuf nodes, nodes4, qnodes, tri, tri_normal, tri_mat, tri_has_vmat, sph, sph_mat, mats, prim_id, cube;
     // per-batch path state (sized by slot capacity / depth): two ray streams (level k reads
     // stream k&1 and writes stream (k+1)&1), hits by stream position, history and path value by slot
-    DevBuf ray_o[2], ray_d[2], thr[2], hits, path_out, hist, counters, ovf, totals;
+    // Two sets: the batches of a frame alternate between two streams (`streams` below), each with its own state.
+    struct PathBufs { DevBuf ray_o[2], ray_d[2], thr[2], hits, path_out, hist, counters, ovf, totals; } pb[2];
     // outputs for the host-pointer entry points
     DevBuf out_mean, out_rgba8, out_rgb8, out_mean_frame, probe_i, probe_t, probe_n;
     std::vector<hipEvent_t> ev;
@@ -192,10 +196,22 @@ MI_API mi_status mi_ctx_create(int device_id, mi_ctx **out) {
             c->ev.push_back(ev);
         }
     }
+    c->n_streams = env_int("MI_TRACER_STREAMS", 1, 2, c->n_streams);
+    c->split_min = env_int("MI_TRACER_SPLIT_MIN", 64, 1 << 30, 4 * std::max(c->tail_threshold, 250000));
+    if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
+        for (hipEvent_t x : c->ev) (void)hipEventDestroy(x);
+        if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+        if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+        if (c->stream2) (void)hipStreamDestroy(c->stream2);
+        delete c;
+        return fail(MI_ERR_HIP, "creating the second stream failed");
+    }
     hipError_t es = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-    if (es != hipSuccess) { for (hipEvent_t x : c->ev) (void)hipEventDestroy(x); delete c; return fail(MI_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(es)); }
-    es = hipHostMalloc((void **)&c->h_totals, kTotals * sizeof(uint64_t), hipHostMallocDefault);
-    if (es != hipSuccess) { for (hipEvent_t x : c->ev) (void)hipEventDestroy(x); (void)hipStreamDestroy(c->stream); delete c; return fail(MI_ERR_HIP, "hipHostMalloc failed: %s", hipGetErrorString(es)); }
+    auto drop_second = [&]() { (void)hipEventDestroy(c->ev_fork); (void)hipEventDestroy(c->ev_join); (void)hipStreamDestroy(c->stream2); };
+    if (es != hipSuccess) { for (hipEvent_t x : c->ev) (void)hipEventDestroy(x); drop_second(); delete c; return fail(MI_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(es)); }
+    es = hipHostMalloc((void **)&c->h_totals, 2 * kTotals * sizeof(uint64_t), hipHostMallocDefault);
+    if (es != hipSuccess) { for (hipEvent_t x : c->ev) (void)hipEventDestroy(x); drop_second(); (void)hipStreamDestroy(c->stream); delete c; return fail(MI_ERR_HIP, "hipHostMalloc failed: %s", hipGetErrorString(es)); }
     *out = c;
     return MI_OK;
 }
@@ -205,13 +221,20 @@ MI_API void mi_ctx_destroy(mi_ctx *c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     DevBuf *all[] = {&c->nodes, &c->nodes4, &c->qnodes, &c->tri, &c->tri_normal, &c->tri_mat, &c->tri_has_vmat, &c->sph, &c->sph_mat, &c->mats,
-                     &c->prim_id, &c->cube, &c->ray_o[0], &c->ray_o[1], &c->ray_d[0], &c->ray_d[1], &c->thr[0], &c->thr[1], &c->hits,
-                     &c->path_out, &c->hist, &c->counters, &c->ovf, &c->totals, &c->out_mean, &c->out_rgba8,
+                     &c->prim_id, &c->cube, &c->out_mean, &c->out_rgba8,
                      &c->out_rgb8, &c->out_mean_frame, &c->probe_i, &c->probe_t, &c->probe_n};
+    for (auto &pb : c->pb) {
+        DevBuf *set[] = {&pb.ray_o[0], &pb.ray_o[1], &pb.ray_d[0], &pb.ray_d[1], &pb.thr[0], &pb.thr[1], &pb.hits, &pb.path_out, &pb.hist, &pb.counters, &pb.ovf, &pb.totals};
+        for (DevBuf *b : set) b->release();
+    }
     for (DevBuf *b : all) b->release();
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     if (c->h_totals) (void)hipHostFree(c->h_totals);
     (void)hipStreamDestroy(c->stream);
+    (void)hipStreamSynchronize(c->stream2);
+    (void)hipStreamDestroy(c->stream2);
+    (void)hipEventDestroy(c->ev_fork);
+    (void)hipEventDestroy(c->ev_join);
     delete c;
 }
 
@@ -893,8 +916,11 @@ struct PathMem {
 // The wavefront loop over all batches of a shard: shared by mi_render_device (buffers grown on demand) and
 // mi_render_device_noalloc (buffers carved out of the static workspace).  timed: per-launch events may be
 // created; sync: wait for the stream and fill *stats (otherwise the work is only enqueued).
-static mi_status render_batches(mi_ctx *c, const mi_render_params *p, const ShardGeom &g, const BatchPlan &bp, const PathMem &m, void *d_rgba_mean,
-                                void *d_rgba8, hipStream_t st, mi_stats *stats, bool timed, bool sync) {
+// n_sets = 2: the batches alternate between the caller's stream (set 0) and the context's second stream (set 1),
+// each with its own path state, so that the sparse end of one batch — the last waves of every launch and the
+// latency-bound k_tail — runs beside the dense start of the next.  Every batch writes its own pixels.
+static mi_status render_batches(mi_ctx *c, const mi_render_params *p, const ShardGeom &g, const BatchPlan &bp, const PathMem *sets, int n_sets,
+                                void *d_rgba_mean, void *d_rgba8, hipStream_t st, mi_stats *stats, bool timed, bool sync) {
     const int64_t local = shard_pixels(g);
     const int spp = g.samples * g.samples;
     const int levels = p->depth + 2; // rays per path <= D+2 (CpuTracer.cu:119-131)
@@ -905,38 +931,45 @@ static mi_status render_batches(mi_ctx *c, const mi_render_params *p, const Shar
     const int sgrid = bp.sgrid;
     const uint32_t segcap = bp.segcap;
     const int64_t n_batches = local > 0 ? (local + npix_b - 1) / npix_b : 0;
+    if (n_batches < 2) n_sets = 1;
     const size_t n_ev = 2 + (size_t)n_batches * levels * 4;
     const bool per_launch = timed && n_ev <= 4096; // per-launch timing only while the event count stays modest
     if (timed) {
         mi_status es = get_events(c, per_launch ? n_ev : 2);
         if (es != MI_OK) return es;
     }
-
-    uint32_t *cnt = m.counters;                                   // cnt[k*kLevelWords + j*MI_CNT_STRIDE] = rays in sub-stream j of level k
-    uint32_t *tail_level = cnt + (kMaxLevels + 1) * kLevelWords;  // 0, or the level at which k_tail took over
-    const RayStream rs[2] = {{m.ray_o[0], m.ray_d[0], m.thr[0], segcap}, {m.ray_o[1], m.ray_d[1], m.thr[1], segcap}};
-    HIPCHK(hipMemsetAsync(m.totals, 0, kTotals * 8, st));
+    hipStream_t streams[2] = {st, c->stream2};
+    for (int s = 0; s < n_sets; s++) HIPCHK(hipMemsetAsync(sets[s].totals, 0, kTotals * 8, st));
     if (sync) HIPCHK(hipEventRecord(c->ev[0], st));
+    if (n_sets > 1) { // fork: the second stream starts behind everything the caller's stream holds so far
+        HIPCHK(hipEventRecord(c->ev_fork, st));
+        HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+    }
     size_t evi = 2;
     for (int64_t b = 0; b < n_batches; b++) {
+        const PathMem &m = sets[b % n_sets];
+        hipStream_t bs = streams[b % n_sets];
+        uint32_t *cnt = m.counters;                                   // cnt[k*kLevelWords + j*MI_CNT_STRIDE] = rays in sub-stream j of level k
+        uint32_t *tail_level = cnt + (kMaxLevels + 1) * kLevelWords;  // 0, or the level at which k_tail took over
+        const RayStream rs[2] = {{m.ray_o[0], m.ray_d[0], m.thr[0], segcap}, {m.ray_o[1], m.ray_d[1], m.thr[1], segcap}};
         const uint32_t pix0 = (uint32_t)(b * npix_b);
         const uint32_t np = (uint32_t)std::min<int64_t>(npix_b, local - (int64_t)pix0);
         const int64_t nslots = (int64_t)np * spp;
         const uint32_t rot0 = deal_rotation((uint32_t)m.egrid0 * (MI_BLOCK / 64), np, spp);
         FastDiv d_np;
         if (!fastdiv_make(np, d_np)) return fail(MI_ERR_INVALID, "internal: division constants failed their check");
-        HIPCHK(hipMemsetAsync(cnt, 0, kCounterWords * 4, st));
+        HIPCHK(hipMemsetAsync(cnt, 0, kCounterWords * 4, bs));
         for (int k = 0; k < levels; k++) {
             const RayStream &sin = rs[k & 1], &sout = rs[(k + 1) & 1];
             unsigned long long *ws = count_work ? (unsigned long long *)m.totals + 2 : nullptr;
-            if (per_launch) HIPCHK(hipEventRecord(c->ev[evi++], st)); // 4 events per level: tail | extend | shade
+            if (per_launch) HIPCHK(hipEventRecord(c->ev[evi++], bs)); // 4 events per level: tail | extend | shade
             if (k >= 1 && c->tail_threshold > 0 && !count_work)
-                hipLaunchKernelGGL(k_tail, dim3(m.tgrid), dim3(MI_BLOCK), 0, st, c->sc, g, pix0, np, d_np, k, p->depth, p->seed, sin, cnt + k * kLevelWords,
+                hipLaunchKernelGGL(k_tail, dim3(m.tgrid), dim3(MI_BLOCK), 0, bs, c->sc, g, pix0, np, d_np, k, p->depth, p->seed, sin, cnt + k * kLevelWords,
                                    (uint32_t)c->tail_threshold, tail_level, m.hist, cap, (size_t)hist_levels * cap, m.path_out, m.ovf,
                                    (unsigned long long *)m.totals + 7, c->shade_min, c->tail_refill);
-            if (per_launch) HIPCHK(hipEventRecord(c->ev[evi++], st));
+            if (per_launch) HIPCHK(hipEventRecord(c->ev[evi++], bs));
 #define MI_EXTEND_ARGS(PRIM)                                                                                                   \
-    dim3((PRIM) ? m.egrid0 : m.egrid), dim3(MI_BLOCK), 0, st, c->sc, (PRIM) ? (const uint32_t *)nullptr : cnt + k * kLevelWords,                   \
+    dim3((PRIM) ? m.egrid0 : m.egrid), dim3(MI_BLOCK), 0, bs, c->sc, (PRIM) ? (const uint32_t *)nullptr : cnt + k * kLevelWords,                   \
         (PRIM) ? (uint32_t)nslots : 0u, segcap, sin.o, sin.d, m.hits, m.ovf, ws,                          \
         (PRIM) ? c->refill_primary : c->refill_min, c->leaf_min, g, pix0, np, d_np, cnt, tail_level, k, (PRIM) ? rot0 : 0u
             if (k == 0) {
@@ -947,24 +980,30 @@ static mi_status render_batches(mi_ctx *c, const mi_render_params *p, const Shar
                 else hipLaunchKernelGGL((k_extend<false, false>), MI_EXTEND_ARGS(false));
             }
 #undef MI_EXTEND_ARGS
-            if (per_launch) HIPCHK(hipEventRecord(c->ev[evi++], st));
+            if (per_launch) HIPCHK(hipEventRecord(c->ev[evi++], bs));
 #define MI_SHADE_ARGS                                                                                                          \
-    dim3(sgrid), dim3(MI_BLOCK), 0, st, c->sc, g, pix0, np, d_np, k, p->depth - k, p->seed, sin, cnt + k * kLevelWords, m.hits,         \
+    dim3(sgrid), dim3(MI_BLOCK), 0, bs, c->sc, g, pix0, np, d_np, k, p->depth - k, p->seed, sin, cnt + k * kLevelWords, m.hits,         \
         m.hist, cap, (size_t)hist_levels * cap, m.path_out, sout, cnt + (k + 1) * kLevelWords, (uint32_t)nslots, tail_level
             if (k == 0) hipLaunchKernelGGL(k_shade<true>, MI_SHADE_ARGS);
             else hipLaunchKernelGGL(k_shade<false>, MI_SHADE_ARGS);
 #undef MI_SHADE_ARGS
-            if (per_launch) HIPCHK(hipEventRecord(c->ev[evi++], st));
+            if (per_launch) HIPCHK(hipEventRecord(c->ev[evi++], bs));
         }
-        hipLaunchKernelGGL(k_resolve, dim3((np + MI_BLOCK - 1) / MI_BLOCK), dim3(MI_BLOCK), 0, st, g, pix0, np, m.path_out,
+        hipLaunchKernelGGL(k_resolve, dim3((np + MI_BLOCK - 1) / MI_BLOCK), dim3(MI_BLOCK), 0, bs, g, pix0, np, m.path_out,
                            (float4 *)d_rgba_mean, (uchar4 *)d_rgba8);
-        hipLaunchKernelGGL(k_sum_counts, dim3(1), dim3(64), 0, st, cnt, levels, m.totals, tail_level);
+        hipLaunchKernelGGL(k_sum_counts, dim3(1), dim3(64), 0, bs, cnt, levels, m.totals, tail_level);
     }
     HIPCHK(hipGetLastError());
+    if (n_sets > 1) { // join: the caller's stream continues when the second stream has finished its batches
+        HIPCHK(hipEventRecord(c->ev_join, c->stream2));
+        HIPCHK(hipStreamWaitEvent(st, c->ev_join, 0));
+    }
     if (!sync) return MI_OK;
-    HIPCHK(hipMemcpyAsync(c->h_totals, m.totals, kTotals * 8, hipMemcpyDeviceToHost, st));
+    for (int s = 0; s < n_sets; s++) HIPCHK(hipMemcpyAsync(c->h_totals + s * kTotals, sets[s].totals, kTotals * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipEventRecord(c->ev[1], st));
     HIPCHK(hipStreamSynchronize(st));
+    for (int s = 1; s < n_sets; s++) // the two sets' totals are sums, except two maxima (slots 4 and 6)
+        for (int k = 0; k < kTotals; k++) c->h_totals[k] = (k == 4 || k == 6) ? std::max(c->h_totals[k], c->h_totals[s * kTotals + k]) : c->h_totals[k] + c->h_totals[s * kTotals + k];
     if (stats) {
         memset(stats, 0, sizeof *stats);
         stats->rays_cast = c->h_totals[0];
@@ -987,6 +1026,8 @@ static mi_status render_batches(mi_ctx *c, const mi_render_params *p, const Shar
         }
         stats->rays_extend = c->h_totals[8];
         if (per_launch) {
+            // With two streams the launches of neighbouring batches overlap: these are the launches' own durations
+            // (what rocprofv3 --kernel-trace reports), and their sum can exceed ms_total.
             double me = 0, msh = 0, mt = 0;
             for (size_t i = 2; i + 4 <= evi; i += 4) {
                 float t0 = 0, a = 0, b2 = 0;
@@ -996,10 +1037,7 @@ static mi_status render_batches(mi_ctx *c, const mi_render_params *p, const Shar
                 mt += t0; me += a; msh += b2;
                 stats->extend_launches++;
             }
-            if (getenv("MI_TRACER_DEBUG_LEVELS")) { // per-launch timings and queue lengths, for tuning only
-                std::vector<uint32_t> hs((kMaxLevels + 1) * kLevelWords), hc(kMaxLevels + 1, 0u);
-                (void)hipMemcpy(hs.data(), cnt, hs.size() * 4, hipMemcpyDeviceToHost); // counts of the LAST batch
-                for (size_t i = 0; i < hs.size(); i += MI_CNT_STRIDE) hc[i / kLevelWords] += hs[i];
+            if (getenv("MI_TRACER_DEBUG_LEVELS")) { // per-launch timings, for tuning only
                 size_t j = 2;
                 for (int64_t b = 0; b < n_batches; b++)
                     for (int k = 0; k < levels; k++, j += 4) {
@@ -1007,8 +1045,7 @@ static mi_status render_batches(mi_ctx *c, const mi_render_params *p, const Shar
                         (void)hipEventElapsedTime(&t0, c->ev[j], c->ev[j + 1]);
                         (void)hipEventElapsedTime(&a, c->ev[j + 1], c->ev[j + 2]);
                         (void)hipEventElapsedTime(&b2, c->ev[j + 2], c->ev[j + 3]);
-                        fprintf(stderr, "batch %lld level %d rays %u tail %.3f ms extend %.3f ms shade %.3f ms\n", (long long)b, k,
-                                b == n_batches - 1 ? hc[k] : 0u, t0, a, b2);
+                        fprintf(stderr, "batch %lld level %d tail %.3f ms extend %.3f ms shade %.3f ms\n", (long long)b, k, t0, a, b2);
                     }
             }
             stats->ms_tail = mt;
@@ -1038,26 +1075,39 @@ MI_API mi_status mi_render_device(mi_ctx *c, const mi_render_params *p, void *d_
     want = std::min<int64_t>(want, (int64_t)1 << 30);
     int64_t npix_b = std::max<int64_t>(64, want / spp / 64 * 64);
     npix_b = std::min(npix_b, std::max<int64_t>(local, 1));
+    // Two streams: a frame that fits one batch is cut into two (each must still be large against the tail
+    // threshold: the point is to overlap one half's sparse end with the other half's dense start), multi-batch frames
+    // alternate as they are.  MI_TRACER_STREAMS=1 keeps everything on the caller's stream.
+    int n_sets = (c->n_streams > 1 && !p->count_work) ? 2 : 1;
+    if (n_sets > 1 && local <= npix_b) {
+        const int64_t half = ((local + 1) / 2 + 63) / 64 * 64;
+        if (half * spp >= c->split_min && half < local) npix_b = half;
+        else n_sets = 1;
+    }
     BatchPlan bp;
     mi_status ps = plan_batch(c, npix_b, spp, p->depth, bp);
     if (ps != MI_OK) return ps;
-    for (int i = 0; i < 2; i++) {
-        HIPCHK(c->ray_o[i].ensure(bp.stream_cap * 16));
-        HIPCHK(c->ray_d[i].ensure(bp.stream_cap * 16));
-        HIPCHK(c->thr[i].ensure(bp.stream_cap * 16));
+    PathMem sets[2];
+    for (int s = 0; s < n_sets; s++) {
+        auto &pb = c->pb[s];
+        for (int i = 0; i < 2; i++) {
+            HIPCHK(pb.ray_o[i].ensure(bp.stream_cap * 16));
+            HIPCHK(pb.ray_d[i].ensure(bp.stream_cap * 16));
+            HIPCHK(pb.thr[i].ensure(bp.stream_cap * 16));
+        }
+        HIPCHK(pb.hits.ensure(bp.stream_cap * 8));
+        HIPCHK(pb.path_out.ensure(bp.cap * 16));
+        HIPCHK(pb.hist.ensure(bp.cap * 32 * bp.hist_levels));
+        HIPCHK(pb.counters.ensure(kCounterWords * 4));
+        HIPCHK(pb.ovf.ensure(stack_bytes(c)));
+        HIPCHK(pb.totals.ensure(kTotals * 8));
+        PathMem &m = sets[s];
+        for (int i = 0; i < 2; i++) { m.ray_o[i] = pb.ray_o[i].as<float4>(); m.ray_d[i] = pb.ray_d[i].as<float4>(); m.thr[i] = pb.thr[i].as<float4>(); }
+        m.hits = pb.hits.as<float2>(); m.path_out = pb.path_out.as<float4>(); m.hist = pb.hist.as<float4>();
+        m.counters = pb.counters.as<uint32_t>(); m.ovf = pb.ovf.as<int>(); m.totals = pb.totals.as<uint64_t>();
+        m.egrid = extend_grid(c); m.egrid0 = c->n_cu * c->extend_wg_primary; m.tgrid = c->n_cu * c->tail_wg_per_cu;
     }
-    HIPCHK(c->hits.ensure(bp.stream_cap * 8));
-    HIPCHK(c->path_out.ensure(bp.cap * 16));
-    HIPCHK(c->hist.ensure(bp.cap * 32 * bp.hist_levels));
-    HIPCHK(c->counters.ensure(kCounterWords * 4));
-    HIPCHK(c->ovf.ensure(stack_bytes(c)));
-    HIPCHK(c->totals.ensure(kTotals * 8));
-    PathMem m;
-    for (int i = 0; i < 2; i++) { m.ray_o[i] = c->ray_o[i].as<float4>(); m.ray_d[i] = c->ray_d[i].as<float4>(); m.thr[i] = c->thr[i].as<float4>(); }
-    m.hits = c->hits.as<float2>(); m.path_out = c->path_out.as<float4>(); m.hist = c->hist.as<float4>();
-    m.counters = c->counters.as<uint32_t>(); m.ovf = c->ovf.as<int>(); m.totals = c->totals.as<uint64_t>();
-    m.egrid = extend_grid(c); m.egrid0 = c->n_cu * c->extend_wg_primary; m.tgrid = c->n_cu * c->tail_wg_per_cu;
-    return render_batches(c, p, g, bp, m, d_rgba_mean, d_rgba8, st, stats, true, true);
+    return render_batches(c, p, g, bp, sets, n_sets, d_rgba_mean, d_rgba8, st, stats, true, true);
 }
 
 // ---- the entry point that allocates nothing (workspace: see `scratch` at the top of this file) ----------
@@ -1121,7 +1171,7 @@ MI_API mi_status mi_render_device_noalloc(mi_ctx *c, const mi_render_params *p, 
     if (off > MI_NOALLOC_BYTES) return fail(MI_ERR_INVALID, "mi_render_device_noalloc: internal sizing error (%zu > %zu)", off, (size_t)MI_NOALLOC_BYTES);
     // Every call on this GPU shares the array and finds the last call's contents in it: what must start at zero
     // (totals, counters) is cleared by render_batches on the stream; everything else is written before it is read.
-    return render_batches(c, p, g, bp, m, d_rgba_mean, d_rgba8, st, stats, false, stats != nullptr);
+    return render_batches(c, p, g, bp, &m, 1, d_rgba_mean, d_rgba8, st, stats, false, stats != nullptr);
 }
 
 MI_API mi_status mi_render(mi_ctx *c, const mi_render_params *p, float *rgba_mean_out, uint8_t *rgb8_out, mi_stats *stats) {
@@ -1220,11 +1270,11 @@ MI_API mi_status mi_assemble_rgb8_device(mi_ctx *c, const mi_render_params *p, c
 static mi_status probe_chunk(mi_ctx *c, int64_t n, int32_t *prim_id_out, float *t_out, float *n_out) {
     hipStream_t st = c->stream;
     hipLaunchKernelGGL((k_extend<false, false>), dim3(extend_grid(c)), dim3(MI_BLOCK), 0, st, c->sc,
-                       (const uint32_t *)nullptr, (uint32_t)n, 0u, c->ray_o[0].as<float4>(), c->ray_d[0].as<float4>(), c->hits.as<float2>(),
-                       c->ovf.as<int>(), (unsigned long long *)nullptr, c->refill_min, c->leaf_min, ShardGeom{}, 0u, 1u, FastDiv{0u, 0u, 0u},
+                       (const uint32_t *)nullptr, (uint32_t)n, 0u, c->pb[0].ray_o[0].as<float4>(), c->pb[0].ray_d[0].as<float4>(), c->pb[0].hits.as<float2>(),
+                       c->pb[0].ovf.as<int>(), (unsigned long long *)nullptr, c->refill_min, c->leaf_min, ShardGeom{}, 0u, 1u, FastDiv{0u, 0u, 0u},
                        (uint32_t *)nullptr, (const uint32_t *)nullptr, 0, 0u);
-    hipLaunchKernelGGL(k_probe_out, dim3((unsigned)((n + MI_BLOCK - 1) / MI_BLOCK)), dim3(MI_BLOCK), 0, st, c->sc, n, c->ray_o[0].as<float4>(),
-                       c->ray_d[0].as<float4>(), c->hits.as<float2>(), c->probe_i.as<int32_t>(), c->probe_t.as<float>(),
+    hipLaunchKernelGGL(k_probe_out, dim3((unsigned)((n + MI_BLOCK - 1) / MI_BLOCK)), dim3(MI_BLOCK), 0, st, c->sc, n, c->pb[0].ray_o[0].as<float4>(),
+                       c->pb[0].ray_d[0].as<float4>(), c->pb[0].hits.as<float2>(), c->probe_i.as<int32_t>(), c->probe_t.as<float>(),
                        n_out ? c->probe_n.as<float>() : nullptr);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(prim_id_out, c->probe_i.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
@@ -1235,13 +1285,13 @@ static mi_status probe_chunk(mi_ctx *c, int64_t n, int32_t *prim_id_out, float *
 }
 
 static mi_status probe_alloc(mi_ctx *c, size_t chunk) {
-    HIPCHK(c->ray_o[0].ensure(chunk * 16));
-    HIPCHK(c->ray_d[0].ensure(chunk * 16));
-    HIPCHK(c->hits.ensure(chunk * 8));
+    HIPCHK(c->pb[0].ray_o[0].ensure(chunk * 16));
+    HIPCHK(c->pb[0].ray_d[0].ensure(chunk * 16));
+    HIPCHK(c->pb[0].hits.ensure(chunk * 8));
     HIPCHK(c->probe_i.ensure(chunk * 4));
     HIPCHK(c->probe_t.ensure(chunk * 4));
     HIPCHK(c->probe_n.ensure(chunk * 12));
-    HIPCHK(c->ovf.ensure(stack_bytes(c)));
+    HIPCHK(c->pb[0].ovf.ensure(stack_bytes(c)));
     return MI_OK;
 }
 
@@ -1257,7 +1307,7 @@ MI_API mi_status mi_trace_primary(mi_ctx *c, int32_t width, int32_t height, int3
     for (int64_t first = 0; first < total; first += chunk) {
         int64_t n = std::min(chunk, total - first);
         hipLaunchKernelGGL(k_generate_primary, dim3((unsigned)((n + MI_BLOCK - 1) / MI_BLOCK)), dim3(MI_BLOCK), 0, c->stream, c->sc, width, height,
-                           samples, first, n, c->ray_o[0].as<float4>(), c->ray_d[0].as<float4>());
+                           samples, first, n, c->pb[0].ray_o[0].as<float4>(), c->pb[0].ray_d[0].as<float4>());
         mi_status ps = probe_chunk(c, n, prim_id_out + first, t_out + first, n_out ? n_out + 3 * first : nullptr);
         if (ps != MI_OK) return ps;
     }
@@ -1280,8 +1330,8 @@ MI_API mi_status mi_trace_rays(mi_ctx *c, int64_t total, const float *rays, int3
             o4[4 * i] = r[0]; o4[4 * i + 1] = r[1]; o4[4 * i + 2] = r[2]; o4[4 * i + 3] = 0;
             d4[4 * i] = r[3]; d4[4 * i + 1] = r[4]; d4[4 * i + 2] = r[5]; d4[4 * i + 3] = 0;
         }
-        HIPCHK(hipMemcpyAsync(c->ray_o[0].p, o4.data(), (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(hipMemcpyAsync(c->ray_d[0].p, d4.data(), (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->pb[0].ray_o[0].p, o4.data(), (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->pb[0].ray_d[0].p, d4.data(), (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
         mi_status ps = probe_chunk(c, n, prim_id_out + first, t_out + first, n_out ? n_out + 3 * first : nullptr);
         if (ps != MI_OK) return ps;
     }
@@ -1305,13 +1355,13 @@ MI_API mi_status mi_occluded_rays(mi_ctx *c, int64_t total, const float *rays, c
             o4[4 * i] = r[0]; o4[4 * i + 1] = r[1]; o4[4 * i + 2] = r[2]; o4[4 * i + 3] = 0;
             d4[4 * i] = r[3]; d4[4 * i + 1] = r[4]; d4[4 * i + 2] = r[5]; d4[4 * i + 3] = tmax[first + i] < MI_NO_HIT ? tmax[first + i] : MI_NO_HIT; // clamp (also NaN) to the reference's "no hit yet" distance
         }
-        HIPCHK(hipMemcpyAsync(c->ray_o[0].p, o4.data(), (size_t)n * 16, hipMemcpyHostToDevice, st));
-        HIPCHK(hipMemcpyAsync(c->ray_d[0].p, d4.data(), (size_t)n * 16, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(c->pb[0].ray_o[0].p, o4.data(), (size_t)n * 16, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(c->pb[0].ray_d[0].p, d4.data(), (size_t)n * 16, hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL((k_extend<false, false, true>), dim3(extend_grid(c)), dim3(MI_BLOCK), 0, st, c->sc, (const uint32_t *)nullptr, (uint32_t)n,
-                           0u, c->ray_o[0].as<float4>(), c->ray_d[0].as<float4>(), c->hits.as<float2>(), c->ovf.as<int>(),
+                           0u, c->pb[0].ray_o[0].as<float4>(), c->pb[0].ray_d[0].as<float4>(), c->pb[0].hits.as<float2>(), c->pb[0].ovf.as<int>(),
                            (unsigned long long *)nullptr, c->refill_min, c->leaf_min, ShardGeom{}, 0u, 1u, FastDiv{0u, 0u, 0u}, (uint32_t *)nullptr,
                            (const uint32_t *)nullptr, 0, 0u);
-        hipLaunchKernelGGL(k_probe_occluded, dim3((unsigned)((n + MI_BLOCK - 1) / MI_BLOCK)), dim3(MI_BLOCK), 0, st, n, c->hits.as<float2>(),
+        hipLaunchKernelGGL(k_probe_occluded, dim3((unsigned)((n + MI_BLOCK - 1) / MI_BLOCK)), dim3(MI_BLOCK), 0, st, n, c->pb[0].hits.as<float2>(),
                            c->probe_i.as<uint8_t>());
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(occluded_out + first, c->probe_i.p, (size_t)n, hipMemcpyDeviceToHost, st));

@@ -6,6 +6,8 @@ golden and fuzz comparisons in contexts of their own (the tuning environment is 
   MI_TRACER_TAIL=0     every level through the per-level kernels (sub-streams, segcap arithmetic,
                        k_shade<false> compaction), k_tail never runs;
   MI_TRACER_TAIL=2000  the hand-over to k_tail happens in the middle of the paths;
+  MI_TRACER_SPLIT_MIN=1000  frames of more than 2000 paths are cut into two batches that run on the context's two
+                       streams (by default only frames of several million paths are), MI_TRACER_STREAMS=1: one stream;
 and runs k_tail on a grid LARGER than k_extend's (MI_TRACER_TAIL_WG_PER_CU=16) on a scene whose
 traversal stacks spill into the global overflow stack.  Reference path: CpuTracer.cu:99-186."""
 import ctypes as C
@@ -25,9 +27,11 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-@pytest.fixture(scope="module", params=[0, 2000], ids=["tail_off", "tail_2000"])
+@pytest.fixture(scope="module", params=[dict(MI_TRACER_TAIL=0), dict(MI_TRACER_TAIL=2000), dict(MI_TRACER_TAIL=2000, MI_TRACER_SPLIT_MIN=1000),
+                                        dict(MI_TRACER_STREAMS=1)],
+                ids=["tail_off", "tail_2000", "two_streams_at_every_size", "one_stream"])
 def ctx_tail(request):
-    with fresh_context(MI_TRACER_TAIL=request.param) as c:
+    with fresh_context(**request.param) as c:
         yield c
 
 
