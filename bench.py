@@ -45,6 +45,8 @@ def main():
                     help="gloo: rehearsal of the N>1 path with several ranks on ONE GPU (tiles staged through the host); never a result")
     ap.add_argument("--check", action="store_true", help="N>1: rank 0 also renders the whole frame alone and compares the assembled frame byte for byte")
     ap.add_argument("--batch-paths", type=int, default=0)
+    ap.add_argument("--streams", type=int, default=2, choices=[1, 2],
+                    help="2 (default): the batches of a frame alternate between two streams; 1: one stream (per-kernel profiling runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
@@ -79,7 +81,7 @@ def main():
         ctx.upload(scene)
     sah_cost = ctx.scene_quality()
 
-    params = P.Context.params(w, h, samples, depth, seed=0, shard=(rank, world), batch_paths=args.batch_paths)
+    params = P.Context.params(w, h, samples, depth, seed=0, shard=(rank, world), batch_paths=args.batch_paths, one_stream=args.streams == 1)
     p0 = P.Context.params(w, h, samples, depth, seed=0, shard=(0, world))
     stride = P.shard_pixels(p0)  # rank 0 owns the most tiles
     rgba8 = torch.zeros(stride * 4, dtype=torch.uint8, device=dev)
@@ -221,22 +223,45 @@ def main():
         bytes_per_ray = 64.0 * nodes_per_ray + 64.0 * leaves_per_ray + 128.0
         flops_per_ray = 108.0 * nodes_per_ray + 37.0 * leaves_per_ray + 160.0
         rays_rank0_per_step = rays_ext / args.steps   # rays traced by k_extend launches (k_tail's excluded)
-        launches_per_step = max(1, n_ext // args.steps)
-        avg_launch_ms = ms_extend / max(1, n_ext)
-        extend_s_per_step = ms_extend / args.steps * 1e-3
+        # Kernel time.  In the timed region the batches of a frame run on two streams and their launches overlap: a launch's
+        # own duration (HIP events on its stream; what rocprofv3 --kernel-trace shows for this same command) then includes
+        # time in which it shares the chip, and the durations of a step add up to more than the step.  The roofline of the
+        # KERNEL is therefore taken from `serial_steps` more steps of the same workload, live, in this process, with every
+        # batch on one stream (MI_RENDER_ONE_STREAM) — each launch alone on the chip; the overlapped figures stay beside it.
+        ovl_launches_per_step = max(1, n_ext // args.steps)
+        ovl_avg_launch_ms = ms_extend / max(1, n_ext)
+        ovl_extend_ms_per_step = ms_extend / args.steps
+        serial_steps = max(3, args.steps // 2)
+        ps1 = P.Context.params(w, h, samples, depth, seed=0, shard=(rank, world), batch_paths=args.batch_paths, one_stream=True)
+        ctx.render_device(ps1, None, rgba8.data_ptr(), stream)
+        s_ms_ext = s_ms_tot = 0.0
+        s_n = s_rays_ext = 0
+        for _ in range(serial_steps):
+            s1 = ctx.render_device(ps1, None, rgba8.data_ptr(), stream)
+            s_ms_ext += s1.ms_extend; s_ms_tot += s1.ms_total; s_n += s1.extend_launches; s_rays_ext += s1.rays_extend
+        rays_rank0_per_step = s_rays_ext / serial_steps
+        launches_per_step = max(1, s_n // serial_steps)
+        avg_launch_ms = s_ms_ext / max(1, s_n)
+        extend_s_per_step = s_ms_ext / serial_steps * 1e-3
         algorithmic_gbs = bytes_per_ray * rays_rank0_per_step / extend_s_per_step / 1e9 if extend_s_per_step > 0 else 0.0
         valu_tflops = flops_per_ray * rays_rank0_per_step / extend_s_per_step / 1e12 if extend_s_per_step > 0 else 0.0
         pmc = pmc_record(args.workload, world, args.bvh)
         roof = {"bound": "valu_issue", "kernel": "k_extend", "achieved": None, "peak": VALU_PEAK_TLANEOPS, "unit": "Tlane-op/s", "frac": None,
                 "traffic": None, "avg_launch_ms": avg_launch_ms, "launches_per_step": launches_per_step,
-                "extend_ms_per_step": extend_s_per_step * 1e3, "extend_share_of_step": (ms_extend / args.steps) / (dt / args.steps * 1e3),
+                "extend_ms_per_step": extend_s_per_step * 1e3, "serial_ms_per_step": s_ms_tot / serial_steps, "serial_steps": serial_steps,
+                "extend_share_of_serial_step": (s_ms_ext / serial_steps) / max(1e-9, s_ms_tot / serial_steps),
+                "timed_region": {"launches_per_step": ovl_launches_per_step, "avg_launch_ms": ovl_avg_launch_ms, "extend_ms_per_step": ovl_extend_ms_per_step,
+                                 "ms_per_step": dt / args.steps * 1e3,
+                                 "note": "launches of the timed region (two streams, neighbouring batches overlap): their own durations, as "
+                                         "rocprofv3 --kernel-trace of this command reports them; they sum to more than the step"},
                 "rays_in_kernel_per_step": rays_rank0_per_step,
                 "algorithmic_gbs": algorithmic_gbs, "algorithmic_hbm_frac": algorithmic_gbs / HBM_PEAK_GBS, "bytes_per_ray": bytes_per_ray,
                 "nodes_per_ray": nodes_per_ray, "prim_tests_per_ray": leaves_per_ray,
                 "valu_tflops": valu_tflops, "valu_flop_frac": valu_tflops / VALU_PEAK_TFLOPS,
                 "note": "bound = VALU issue: frac = active-lane VALU operations per second / (1024 SIMDs x 32 lanes per clock x 2.4 GHz = fp32 vector "
                         "peak 157.3 TFLOP/s / 2); lane operations per frame from the committed PMC pass (SQ_THREAD_CYCLES_VALU), time live from "
-                        "HIP events.  frac_4cycle_slots is the same product priced at one wave64 instruction per 4 cycles per SIMD with the "
+                        "HIP events over serial_steps steps with every batch on ONE stream (each launch alone on the chip; in the timed region "
+                        "the launches of two streams overlap, see timed_region and frac_timed_region; step_valu_frac is the whole step).  frac_4cycle_slots is the same product priced at one wave64 instruction per 4 cycles per SIMD with the "
                         "clock the PMC pass measured (VALU instruction rate x active lanes / 64).  algorithmic_gbs = SURVEY 8(d) bytes / "
                         "k_extend time: the scene is L1/L2/LDS resident, so that figure is not a roof that binds (hbm_counter_frac is)."}
         if pmc:
@@ -251,6 +276,10 @@ def main():
                          "hbm_counter_gbs": ke["hbm_bytes_sum"] / extend_s_per_step / 1e9, "hbm_counter_frac": ke["hbm_bytes_sum"] / extend_s_per_step / 1e9 / HBM_PEAK_GBS,
                          "l2_read_gbs": ke["l2_read_bytes_sum"] / extend_s_per_step / 1e9, "l2_read_frac": ke["l2_read_bytes_sum"] / extend_s_per_step / 1e9 / L2_PEAK_GBS,
                          "l2_hit": ke["l2_hit"], "l1_hit": ke["l1_hit"], "pmc_clock_ghz": ke.get("eff_clock_ghz"),
+                         # the whole step, overlap included: active-lane VALU operations of every render kernel of a frame / the timed step
+                         "step_valu_frac": sum((pmc.get(k) or {}).get("lane_ops_sum", 0.0) for k in ("k_extend", "k_shade", "k_tail"))
+                                           / (dt_max / args.steps) / 1e12 / VALU_PEAK_TLANEOPS,
+                         "frac_timed_region": ke["lane_ops_sum"] / (ovl_extend_ms_per_step * 1e-3) / 1e12 / VALU_PEAK_TLANEOPS if ovl_extend_ms_per_step > 0 else None,
                          "pmc": {"source": pmc["source"], "k_extend_by_level": ke["by_level"],
                                  "k_shade": {k: v for k, v in (pmc.get("k_shade") or {}).items() if k != "by_level"},
                                  "k_tail": {k: v for k, v in (pmc.get("k_tail") or {}).items() if k != "by_level"}}})
@@ -276,7 +305,7 @@ def main():
                        "sharding": f"image tiles 32x32, tile k -> rank k % {world}, BVH replicated; sample-range sharding + sum-reduce not built "
                                    "(a reduce over ranks would round differently from the reference's per-pixel sample order)",
                        "exchange": None if world == 1 else ("RCCL gather of RGBA8 tiles to rank 0" if args.backend == "nccl" else "REHEARSAL: gloo, all ranks on one GPU"),
-                       "rays_per_step": rays_all / args.steps},
+                       "rays_per_step": rays_all / args.steps, "streams": args.streams},
             "roofline": roof,
         }
         if phases:
@@ -284,7 +313,7 @@ def main():
         if world == 1:
             # the Tracer boundary hands back HOST bytes (HipTracer::traceImage -> mi_render): the same frame with the RGB8 copy to a
             # pageable host buffer, PCIe-inclusive; never `value`
-            pf = P.Context.params(w, h, samples, depth, seed=0)
+            pf = P.Context.params(w, h, samples, depth, seed=0, one_stream=args.streams == 1)
             ctx.render(pf, want_mean=False)
             t1 = time.perf_counter()
             rh = 0

@@ -115,8 +115,13 @@ typedef struct mi_render_params {
     int32_t count_work;   /* != 0: run the instrumented extend kernel that counts node
                              visits and primitive tests (slower; for roofline
                              accounting, never inside a timed region)                */
-    int32_t reserved;
+    int32_t flags;        /* MI_RENDER_* bits, 0 = defaults                            */
 } mi_render_params;
+/* The batches of a frame normally alternate between two streams, each with its own path state (a frame that
+ * fits one batch is cut in two), so that the sparse end of one batch runs beside the dense start of the next;
+ * the image does not depend on it.  This bit keeps every batch on the one stream of the call: each kernel then
+ * has the chip to itself, which is what a per-kernel measurement wants. */
+#define MI_RENDER_ONE_STREAM 1
 
 typedef struct mi_stats {
     uint64_t rays_cast;      /* closest-hit queries issued (primary + bounce)       */

@@ -21,6 +21,7 @@ class MiError(RuntimeError):
 
 
 MI_OK, MI_ERR_INVALID, MI_ERR_NO_DEVICE, MI_ERR_HIP, MI_ERR_NO_SCENE, MI_ERR_OOM = range(6)
+MI_RENDER_ONE_STREAM = 1
 
 c_float_p = C.POINTER(C.c_float)
 c_u32_p = C.POINTER(C.c_uint32)
@@ -47,7 +48,7 @@ class RenderParams(C.Structure):
         ("width", C.c_int32), ("height", C.c_int32), ("samples_per_dim", C.c_int32), ("depth", C.c_int32),
         ("seed", C.c_uint64), ("tile_w", C.c_int32), ("tile_h", C.c_int32),
         ("shard_rank", C.c_int32), ("shard_count", C.c_int32), ("batch_paths", C.c_int64),
-        ("count_work", C.c_int32), ("reserved", C.c_int32),
+        ("count_work", C.c_int32), ("flags", C.c_int32),
     ]
 
 

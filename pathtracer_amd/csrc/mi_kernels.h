@@ -347,9 +347,7 @@ __device__ __forceinline__ bool tie_allows(const DevScene &sc, int best_slot, in
 // record are issued together (one memory round trip instead of two) and the reject
 // tests of :92, :96 and :104 — each a pure function of the same values — are combined
 // at the end.  The accepted (t, u, v) are the reference's.
-__device__ __forceinline__ void tri_test(const DevScene &sc, int slot, f3 o, f3 d, Hit &h) {
-    const char *rec = (const char *)sc.tri + ((uint32_t)slot << 6);
-    float4 v0 = *(const float4 *)(rec), ui = *(const float4 *)(rec + 16), vi = *(const float4 *)(rec + 32), ni = *(const float4 *)(rec + 48);
+__device__ __forceinline__ void tri_test_rec(const DevScene &sc, int slot, float4 v0, float4 ui, float4 vi, float4 ni, f3 o, f3 d, Hit &h) {
     f3 p = o - xyz(v0);
     float pz = dot3w(xyz(ni), p);
     float dz = dot3w(xyz(ni), d);
@@ -361,9 +359,13 @@ __device__ __forceinline__ void tri_test(const DevScene &sc, int slot, f3 o, f3 
     if (ok && t == h.t) ok = tie_allows(sc, h.slot, slot, true);
     if (ok) { h.t = t; h.slot = slot; }
 }
+__device__ __forceinline__ void tri_test(const DevScene &sc, int slot, f3 o, f3 d, Hit &h) {
+    const char *rec = (const char *)sc.tri + ((uint32_t)slot << 6);
+    float4 v0 = *(const float4 *)(rec), ui = *(const float4 *)(rec + 16), vi = *(const float4 *)(rec + 32), ni = *(const float4 *)(rec + 48);
+    tri_test_rec(sc, slot, v0, ui, vi, ni, o, d, h);
+}
 
-__device__ __forceinline__ void sphere_test(const DevScene &sc, int slot, f3 o, f3 d, Hit &h) { // sphere.cu:5-35
-    float4 cr = sc.sph[slot - (int)sc.n_tri];
+__device__ __forceinline__ void sphere_test_rec(const DevScene &sc, int slot, float4 cr, f3 o, f3 d, Hit &h) { // sphere.cu:5-35
     f3 dir = normalize3(d);
     f3 to = xyz(cr) - o;
     float dt = dot3(dir, to);
@@ -379,6 +381,7 @@ __device__ __forceinline__ void sphere_test(const DevScene &sc, int slot, f3 o, 
     else return;
     h.t = t; h.slot = slot;
 }
+__device__ __forceinline__ void sphere_test(const DevScene &sc, int slot, f3 o, f3 d, Hit &h) { sphere_test_rec(sc, slot, sc.sph[slot - (int)sc.n_tri], o, d, h); }
 
 __device__ __forceinline__ void prim_test(const DevScene &sc, int slot, f3 o, f3 d, Hit &h) { // geometry.h:26-29
     if ((uint32_t)slot >= sc.n_tri) sphere_test(sc, slot, o, d, h);
@@ -430,11 +433,11 @@ __device__ __forceinline__ bool tail_took_over(const uint32_t *tail_level, int l
 }
 
 #define MI_DONE 0x7fffffff
-#define MI_NONE (-1)
+#define MI_NONE 0x7ffffffe // "pop next": no valid ref (node indices and leaf refs are below 2^26 in magnitude)
 // Per-lane traversal state of the persistent kernels.
 struct Lane {
     f3 o, d;
-    f3 ia, ic;        // fast slab test: distance to the plane of code F on axis a = F * ia.a + ic.a
+    float2 ax, ay, az; // fast slab test: (ia, ic) per axis, the distance to the plane of code F on that axis = F * ia + ic
     uint32_t seln[3]; // v_perm selector of the near plane on each axis
     Hit h;
     int cur, sp; // cur: >= 0 node to visit, < 0 leaf ~cur to test, MI_DONE finished
@@ -450,8 +453,9 @@ __device__ __forceinline__ void lane_start(const DevScene &sc, Lane &L, f3 o, f3
     // (coordinates are < 1e15), so no inf - inf or 0 * inf can arise in the slab test.
     const f3 inv = mk3(__builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(d.x), -1e18f, 1e18f), __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(d.y), -1e18f, 1e18f),
                        __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(d.z), -1e18f, 1e18f));
-    L.ia = mk3(sc.qs[0] * inv.x, sc.qs[1] * inv.y, sc.qs[2] * inv.z);
-    L.ic = mk3((sc.qb[0] - o.x) * inv.x, (sc.qb[1] - o.y) * inv.y, (sc.qb[2] - o.z) * inv.z);
+    L.ax = make_float2(sc.qs[0] * inv.x, (sc.qb[0] - o.x) * inv.x);
+    L.ay = make_float2(sc.qs[1] * inv.y, (sc.qb[1] - o.y) * inv.y);
+    L.az = make_float2(sc.qs[2] * inv.z, (sc.qb[2] - o.z) * inv.z);
     L.seln[0] = inv.x < 0.0f ? MI_Q_SEL_HI : MI_Q_SEL_LO;
     L.seln[1] = inv.y < 0.0f ? MI_Q_SEL_HI : MI_Q_SEL_LO;
     L.seln[2] = inv.z < 0.0f ? MI_Q_SEL_HI : MI_Q_SEL_LO;
@@ -490,13 +494,26 @@ __device__ __forceinline__ void cswap(bool sw, float &ka, float &kb, int &ra, in
     const int r0 = sw ? rb : ra, r1 = sw ? ra : rb;
     ka = k0; kb = k1; ra = r0; rb = r1;
 }
-__device__ __forceinline__ void node_phase(const DevScene &sc, Lane &L, lds_int *stack, int *my_ovf, size_t ovf_stride, const uint4 *treelet) {
-    // one generic (flat) load per 16 B serves both: lanes at the top of the tree read the LDS
-    // copy, the others global memory
-    const char *nd = L.cur >= sc.treelet_base ? (const char *)treelet + ((uint32_t)(L.cur - sc.treelet_base) << 6)
-                                               : (const char *)sc.qnodes + ((uint32_t)L.cur << 6);
-    const uint4 px = *(const uint4 *)(nd), py = *(const uint4 *)(nd + 16), pz = *(const uint4 *)(nd + 32);
-    const int4 refs = *(const int4 *)(nd + 48);
+// Where node i lives, as one generic address: the treelet copy in LDS for i >= treelet_base, global memory otherwise.
+// NodeBase holds what does not depend on i: the global base, and for the treelet the 64-bit difference between the
+// flat address of the LDS copy of node treelet_base and the global address that index would have — so the address
+// is base + (i << 6) (+ delta in the treelet): a compare, two selects and two 64-bit adds instead of the dozen
+// instructions of a select between two pointers.
+struct NodeBase {
+    uint64_t base, delta;
+};
+__device__ __forceinline__ NodeBase node_base(const DevScene &sc, const uint4 *treelet) {
+    const uint64_t g = (uint64_t)(uintptr_t)sc.qnodes;
+    const uint64_t l = (uint64_t)(uintptr_t)treelet; // generic (flat) address of the LDS array
+    return NodeBase{g, l - g - ((uint64_t)(uint32_t)sc.treelet_base << 6)};
+}
+__device__ __forceinline__ const char *node_addr(const DevScene &sc, int cur, const NodeBase &nb) {
+    return (const char *)(uintptr_t)(nb.base + ((uint64_t)(uint32_t)cur << 6) + (cur >= sc.treelet_base ? nb.delta : 0ull));
+}
+// Box tests, ordering and pushes of a node whose 64 B are in registers.  POP = false: when no child is hit the lane
+// is left with L.cur = MI_NONE and the caller pops (merged_step, which pops once for leaf and node lanes).
+template <bool POP>
+__device__ __forceinline__ void node_process(const DevScene &sc, Lane &L, lds_int *stack, int *my_ovf, size_t ovf_stride, uint4 px, uint4 py, uint4 pz, int4 refs) {
     const uint32_t PX[4] = {px.x, px.y, px.z, px.w}, PY[4] = {py.x, py.y, py.z, py.w}, PZ[4] = {pz.x, pz.y, pz.z, pz.w};
     int R[4] = {refs.x, refs.y, refs.z, refs.w};
     float K[4]; // entry distance of a child that is hit, +inf otherwise
@@ -504,7 +521,7 @@ __device__ __forceinline__ void node_phase(const DevScene &sc, Lane &L, lds_int 
 #pragma unroll
     for (int c = 0; c < 4; c++) {
         float tmin;
-        const bool hit = slab_fast_q(PX[c], PY[c], PZ[c], L.seln, self, L.ia, L.ic, L.h.t, tmin);
+        const bool hit = slab_fast_q(PX[c], PY[c], PZ[c], L.seln, self, mk3(L.ax.x, L.ay.x, L.az.x), mk3(L.ax.y, L.ay.y, L.az.y), L.h.t, tmin);
         K[c] = hit ? tmin : __builtin_inff(); // an empty seat's box is inverted on every axis: never hit
     }
 #ifdef MI_DUMMY_VALU
@@ -536,15 +553,51 @@ __device__ __forceinline__ void node_phase(const DevScene &sc, Lane &L, lds_int 
         sp += K[2] < inf ? 1 : 0;
         L.sp = sp;
         if (K[3] < inf) L.cur = R[3];
-        else lane_pop(L, stack, my_ovf, ovf_stride);
+        else if (POP) lane_pop(L, stack, my_ovf, ovf_stride);
+        else L.cur = MI_NONE;
     } else if (K[3] < inf) {
         if (K[0] < inf) lane_push(L, stack, my_ovf, ovf_stride, R[0]);
         if (K[1] < inf) lane_push(L, stack, my_ovf, ovf_stride, R[1]);
         if (K[2] < inf) lane_push(L, stack, my_ovf, ovf_stride, R[2]);
         L.cur = R[3];
-    } else {
+    } else if (POP) {
         lane_pop(L, stack, my_ovf, ovf_stride);
+    } else {
+        L.cur = MI_NONE;
     }
+}
+__device__ __forceinline__ void node_phase(const DevScene &sc, Lane &L, lds_int *stack, int *my_ovf, size_t ovf_stride, const NodeBase &nb) {
+    // one generic (flat) load per 16 B serves both: lanes at the top of the tree read the LDS
+    // copy, the others global memory
+    const char *nd = node_addr(sc, L.cur, nb);
+    const uint4 px = *(const uint4 *)(nd), py = *(const uint4 *)(nd + 16), pz = *(const uint4 *)(nd + 32);
+    const int4 refs = *(const int4 *)(nd + 48);
+    node_process<true>(sc, L, stack, my_ovf, ovf_stride, px, py, pz, refs);
+}
+// Leaf lanes and node lanes in ONE step (draining waves and k_tail, whose time is a chain of latencies): every lane
+// with work fetches the 64 B its ref names — a quantised node, a triangle record, or a sphere (16 B used; the
+// sphere array is padded so that the 64-B read stays inside it) — with the same four loads, the wave waits once,
+// both kinds compute, and one stack read serves every lane that needs its next ref.  (Two separate phases per
+// iteration paid two memory round trips and two stack round trips.)  ANY: the first accepted primitive ends the query.
+template <bool ANY>
+__device__ __forceinline__ void merged_step(const DevScene &sc, Lane &L, lds_int *stack, int *my_ovf, size_t ovf_stride, const NodeBase &nb, bool want_leaf,
+                                            bool want_node) {
+    if (!(want_leaf || want_node)) return;
+    const int slot = ~L.cur;
+    const bool is_sph = want_leaf && (uint32_t)slot >= sc.n_tri;
+    const char *at = want_node ? node_addr(sc, L.cur, nb)
+                               : (is_sph ? (const char *)sc.sph + ((uint32_t)(slot - (int)sc.n_tri) << 4) : (const char *)sc.tri + ((uint32_t)slot << 6));
+    const uint4 r0 = *(const uint4 *)(at), r1 = *(const uint4 *)(at + 16), r2 = *(const uint4 *)(at + 32), r3 = *(const uint4 *)(at + 48);
+    auto f4 = [](uint4 r) { return make_float4(__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w)); };
+    if (want_leaf) {
+        if (is_sph) sphere_test_rec(sc, slot, f4(r0), L.o, L.d, L.h);
+        else tri_test_rec(sc, slot, f4(r0), f4(r1), f4(r2), f4(r3), L.o, L.d, L.h);
+        L.cur = MI_NONE;
+        if (ANY && L.h.slot >= 0) { L.cur = MI_DONE; L.sp = 0; }
+    } else {
+        node_process<false>(sc, L, stack, my_ovf, ovf_stride, r0, r1, r2, make_int4((int)r3.x, (int)r3.y, (int)r3.z, (int)r3.w));
+    }
+    if (L.cur == MI_NONE) lane_pop(L, stack, my_ovf, ovf_stride);
 }
 __device__ __forceinline__ void leaf_phase(const DevScene &sc, Lane &L, lds_int *stack, int *my_ovf, size_t ovf_stride) { // one primitive
     prim_test(sc, ~L.cur, L.o, L.d, L.h);
@@ -577,8 +630,11 @@ __device__ __forceinline__ void leaf_phase(const DevScene &sc, Lane &L, lds_int 
 // *primary_count (it is the level-0 ray count).
 // ANY = true is the any-hit (occlusion) query: ray_d[i].w is the ray's maximum distance,
 // the lane stops at the first accepted primitive, and hits[i].y >= 0 means "occluded".
+#ifndef MI_EXTEND_WG
+#define MI_EXTEND_WG 6
+#endif
 template <bool COUNT, bool PRIMARY, bool ANY = false>
-__global__ void __launch_bounds__(MI_BLOCK, 6)
+__global__ void __launch_bounds__(MI_BLOCK, PRIMARY ? 6 : MI_EXTEND_WG)
 k_extend(DevScene sc, const uint32_t *count_ptr, uint32_t fixed_count, uint32_t segcap,
          const float4 *ray_o, const float4 *ray_d, float2 *hits, int *ovf, unsigned long long *work_stats, int refill_min,
          int leaf_min, ShardGeom g, uint32_t pix0, uint32_t npix, FastDiv d_npix, uint32_t *primary_count,
@@ -588,6 +644,7 @@ k_extend(DevScene sc, const uint32_t *count_ptr, uint32_t fixed_count, uint32_t 
     __shared__ uint4 lds_treelet[MI_TREELET * 4];
     for (int i = threadIdx.x; i < sc.treelet_count * 4; i += MI_BLOCK) lds_treelet[i] = sc.qnodes[(size_t)sc.treelet_base * 4 + i];
     __syncthreads();
+    const NodeBase nbase = node_base(sc, lds_treelet);
 
     const int lane = threadIdx.x & 63;
     lds_int *stack = (lds_int *)lds_stack + threadIdx.x;
@@ -615,7 +672,8 @@ k_extend(DevScene sc, const uint32_t *count_ptr, uint32_t fixed_count, uint32_t 
     Lane L;
     L.cur = MI_DONE; L.sp = 0;
     L.h = Hit{MI_NO_HIT, -1};
-    L.o = L.d = L.ia = L.ic = mk3(0, 0, 0);
+    L.o = L.d = mk3(0, 0, 0);
+    L.ax = L.ay = L.az = make_float2(0.0f, 0.0f);
     L.seln[0] = L.seln[1] = L.seln[2] = MI_Q_SEL_LO;
     unsigned long long act = 0ull; // ballot of `active`
     // Level 0: the camera rays of a chunk are computed by all 64 lanes at once when the wave
@@ -697,15 +755,9 @@ k_extend(DevScene sc, const uint32_t *count_ptr, uint32_t fixed_count, uint32_t 
         if (!more) {
             // Draining (no rays left to refill with): the wave's remaining time is a latency
             // chain, so every lane advances every iteration, leaves and nodes both.
-            if (want_leaf) {
-                if (COUNT) n_leaves++;
-                leaf_phase(sc, L, stack, my_ovf, ovf_stride);
-                if (ANY && L.h.slot >= 0) { L.cur = MI_DONE; L.sp = 0; }
-            }
-            if (want_node) {
-                if (COUNT) { n_nodes++; ray_steps++; }
-                node_phase(sc, L, stack, my_ovf, ovf_stride, lds_treelet);
-            }
+            if (COUNT && want_leaf) n_leaves++;
+            if (COUNT && want_node) { n_nodes++; ray_steps++; }
+            merged_step<ANY>(sc, L, stack, my_ovf, ovf_stride, nbase, want_leaf, want_node);
         } else if (nl > 0 && (nl >= leaf_min || nn == 0)) {
             if (want_leaf) {
                 if (COUNT) n_leaves++;
@@ -717,7 +769,7 @@ k_extend(DevScene sc, const uint32_t *count_ptr, uint32_t fixed_count, uint32_t 
                 n_nodes++;
                 ray_steps++;
             }
-            node_phase(sc, L, stack, my_ovf, ovf_stride, lds_treelet);
+            node_phase(sc, L, stack, my_ovf, ovf_stride, nbase);
         }
         if (active && L.cur == MI_DONE) {
             hits[slot] = make_float2(L.h.t, __int_as_float(L.h.slot));
@@ -1043,6 +1095,7 @@ k_tail(DevScene sc, ShardGeom g, uint32_t pix0, uint32_t npix, FastDiv d_npix, i
     __shared__ uint4 lds_treelet[MI_TREELET * 4];
     for (int i = threadIdx.x; i < sc.treelet_count * 4; i += MI_BLOCK) lds_treelet[i] = sc.qnodes[(size_t)sc.treelet_base * 4 + i];
     __syncthreads();
+    const NodeBase nbase = node_base(sc, lds_treelet);
     const int lane = threadIdx.x & 63;
     if (blockIdx.x == 0 && threadIdx.x == 0) *tail_level = (uint32_t)level0;
     lds_int *stack = (lds_int *)lds_stack + threadIdx.x;
@@ -1063,7 +1116,8 @@ k_tail(DevScene sc, ShardGeom g, uint32_t pix0, uint32_t npix, FastDiv d_npix, i
     Lane L;
     L.cur = MI_DONE; L.sp = 0;
     L.h = Hit{MI_NO_HIT, -1};
-    L.o = L.d = L.ia = L.ic = mk3(0, 0, 0);
+    L.o = L.d = mk3(0, 0, 0);
+    L.ax = L.ay = L.az = make_float2(0.0f, 0.0f);
     L.seln[0] = L.seln[1] = L.seln[2] = MI_Q_SEL_LO;
     unsigned long long act = 0ull;
     bool more = true; // wave-uniform
@@ -1121,8 +1175,7 @@ k_tail(DevScene sc, ShardGeom g, uint32_t pix0, uint32_t npix, FastDiv d_npix, i
         } else {
             // The tail is a latency chain (few rays, whole paths per lane): leaves and nodes
             // both advance in every iteration (1.19 -> 1.04 ms on C3).
-            if (want_leaf) leaf_phase(sc, L, stack, my_ovf, ovf_stride);
-            if (want_node) node_phase(sc, L, stack, my_ovf, ovf_stride, lds_treelet);
+            merged_step<false>(sc, L, stack, my_ovf, ovf_stride, nbase, want_leaf, want_node);
         }
         act = __ballot(active);
     } while (more || act != 0ull);

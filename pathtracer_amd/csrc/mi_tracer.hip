@@ -111,7 +111,7 @@ struct mi_ctx {
     int shade_min = 24;         // MI_TRACER_SHADE_MIN: lanes waiting to be shaded that trigger a shade phase of k_tail
     int shade_wg_per_cu = 8;    // MI_TRACER_SHADE_WG_PER_CU: workgroups of k_shade per CU (grid-stride loop)
     int tail_wg_per_cu = 4;     // workgroups of k_tail resident per CU (occupancy query at context creation)
-    int tail_threshold = 1500000; // MI_TRACER_TAIL: k_tail takes over a batch once a level has at most this many rays (0 = off)
+    int tail_threshold = 700000;  // MI_TRACER_TAIL: k_tail takes over a batch once a level has at most this many rays (0 = off); with the batches on two streams 0.5-1 M measure alike on C3, 1.5 M 2 % slower (8 % on C5)
 };
 
 static const int kMaxLevels = 64; // counters reserved per batch (depth + 2 must fit)
@@ -132,7 +132,7 @@ static int extend_grid(const mi_ctx *c) { return c->n_cu * c->extend_wg_per_cu; 
 static int stack_grid(const mi_ctx *c) { return c->n_cu * std::max(c->extend_wg_per_cu, std::max(c->extend_wg_primary, c->tail_wg_per_cu)); }
 static size_t stack_bytes(const mi_ctx *c) { return (size_t)(MI_MAX_STACK - MI_LDS_STACK) * stack_grid(c) * MI_BLOCK * 4; }
 
-MI_API int mi_abi_version(void) { return 10; }
+MI_API int mi_abi_version(void) { return 11; }
 MI_API const char *mi_last_error(void) { return g_err.c_str(); }
 
 MI_API mi_status mi_ctx_create(int device_id, mi_ctx **out) {
@@ -387,6 +387,8 @@ static mi_status upload_prims(mi_ctx *c, const mi_scene_soa *s) {
     HIPCHK(up(c->tri_normal, s->tri_normal, nt * 16));
     HIPCHK(up(c->tri_mat, s->tri_mat, nt * 12));
     HIPCHK(up(c->tri_has_vmat, s->tri_has_vmat, nt));
+    // + 64 B: merged_step reads 64 B at a sphere's record like at a triangle's or a node's and uses the first 16
+    HIPCHK(c->sph.ensure(ns * 16 + 64));
     HIPCHK(up(c->sph, s->sph_center_radius, ns * 16));
     HIPCHK(up(c->sph_mat, s->sph_mat, ns * 4));
     HIPCHK(up(c->mats, s->materials, (size_t)s->n_mat * 80));
@@ -655,7 +657,7 @@ MI_API mi_status mi_scene_upload_build(mi_ctx *c, const mi_scene_soa *s, const f
             HIPCHK(r_nrm.ensure(std::max<size_t>(nt * 16, 16)));
             HIPCHK(r_mat.ensure(std::max<size_t>(nt * 12, 16)));
             HIPCHK(r_vm.ensure(std::max<size_t>(nt, 16)));
-            HIPCHK(r_sph.ensure(std::max<size_t>(ns * 16, 16)));
+            HIPCHK(r_sph.ensure(ns * 16 + 64)); // padded like c->sph (upload_prims)
             HIPCHK(r_smat.ensure(std::max<size_t>(ns * 4, 16)));
             HIPCHK(r_id.ensure((size_t)n * 4));
             HIPCHK(nb.ensure((size_t)n * sizeof(BuildBox))); // permuted boxes (nb is free until the fit)
@@ -1078,7 +1080,7 @@ MI_API mi_status mi_render_device(mi_ctx *c, const mi_render_params *p, void *d_
     // Two streams: a frame that fits one batch is cut into two (each must still be large against the tail
     // threshold: the point is to overlap one half's sparse end with the other half's dense start), multi-batch frames
     // alternate as they are.  MI_TRACER_STREAMS=1 keeps everything on the caller's stream.
-    int n_sets = (c->n_streams > 1 && !p->count_work) ? 2 : 1;
+    int n_sets = (c->n_streams > 1 && !p->count_work && !(p->flags & MI_RENDER_ONE_STREAM)) ? 2 : 1;
     if (n_sets > 1 && local <= npix_b) {
         const int64_t half = ((local + 1) / 2 + 63) / 64 * 64;
         if (half * spp >= c->split_min && half < local) npix_b = half;

@@ -1,7 +1,9 @@
 # usage (on the GPU box, from the repo root):  bash profiles/tools/collect.sh <tag> [workload]
 # Raw rocprofv3 output goes to gpurun_out/<tag>/; profiles/tools/pmc_to_json.py turns it into the JSON bench.py reads.
 # Passes (each its own run, counters never combined with a trace):
-#   stats : --kernel-trace --stats of `bench.py --steps 10 --warmup 3 --no-cpu-baseline`  (durations)
+#   stats : --kernel-trace --stats of `bench.py --streams 1 --steps 10 --warmup 3 --no-cpu-baseline`: every batch on one
+#           stream, each launch alone on the chip (per-level durations for the JSON; k_extend's average = roofline.avg_launch_ms)
+#   stats2: the same of the default command `bench.py --steps 10 --warmup 3 --no-cpu-baseline` (two streams; launches overlap)
 #   fetch / write : HBM-side bytes (FETCH_SIZE, WRITE_SIZE)          of ONE frame (profiles/tools/one_frame.py)
 #   sq    : VALU issue and lane counters, wave cycles                 "
 #   tcc / tcp : L2 and vector-L1 requests                             "
@@ -13,7 +15,8 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/stats -o run --output-format csv -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --workload $WL > $OUT/bench_profiled.json 2> $OUT/stats.log
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/stats -o run --output-format csv -- python $R/bench.py --streams 1 --steps 10 --warmup 3 --no-cpu-baseline --workload $WL > $OUT/bench_profiled_one_stream.json 2> $OUT/stats.log
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/stats2 -o run --output-format csv -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --workload $WL > $OUT/bench_profiled.json 2> $OUT/stats2.log
 pass() { # name, counters...
     n=$1; shift
     timeout -s KILL 180 rocprofv3 --pmc "$@" -d $OUT/$n -o run --output-format csv -- python $R/profiles/tools/one_frame.py $WL > $OUT/$n.out 2> $OUT/$n.log

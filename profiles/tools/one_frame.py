@@ -18,5 +18,5 @@ if len(sys.argv) > 2 and sys.argv[2] == "device":
     ctx.upload_build(sc)
 else:
     ctx.upload(sc)
-st = ctx.render_device(P.Context.params(w, h, samples, depth), None, None)
+st = ctx.render_device(P.Context.params(w, h, samples, depth, one_stream=True), None, None)  # one stream: one dispatch per level
 print(name, st.ms_total, st.ms_extend, st.rays_cast)
