@@ -314,6 +314,26 @@ typedef struct mi_cubemap {
 } mi_cubemap;
 mi_status mi_cubemap_upload(mi_ctx *ctx, const mi_cubemap *cm);
 
+/* Several GPUs in ONE process behind the Tracer interface ("one ctx = one process, N devices"; no
+ * counterpart in the reference, which drives one device, GpuTracer.cu:165-181).  A group holds one context per
+ * device, the scene replicated on each; mi_group_render makes device k render shard k of n (tiles k mod n, as
+ * mi_render_params.shard_* describe), moves the tonemapped RGBA8 tiles to the first device with RCCL (grouped
+ * ncclSend / ncclRecv on an ncclCommInitAll communicator: device to device over xGMI, no host staging), assembles
+ * the frame there and copies it to rgb8_out (HOST, uint8[width*height*3], tracer.cu:96 layout).  The image is
+ * bit-identical to a one-device render for any n.  librccl.so is loaded when the first group is created.
+ * stats: rays / paths summed over the devices, kernel times of the slowest device, ms_total = wall clock of the
+ * call, ms_other = exchange + assembly.  params->shard_count must be 0 or 1.
+ * Verified on hardware with n = 1 only (one GPU per lease): the n > 1 exchange is the same code, unverified. */
+typedef struct mi_group mi_group;
+mi_status mi_group_create(const int *device_ids, int n_dev, mi_group **out);
+void mi_group_destroy(mi_group *group);
+int mi_group_size(const mi_group *group);
+mi_status mi_group_scene_upload(mi_group *group, const mi_scene_soa *scene);
+mi_status mi_group_scene_upload_build(mi_group *group, const mi_scene_soa *scene, const float *tri_verts,
+                                      mi_build_stats *stats);
+mi_status mi_group_cubemap_upload(mi_group *group, const mi_cubemap *cm);
+mi_status mi_group_render(mi_group *group, const mi_render_params *params, uint8_t *rgb8_out, mi_stats *stats);
+
 /* Thread-local description of the last error returned on this thread. */
 const char *mi_last_error(void);
 

@@ -76,6 +76,8 @@ MI_SYMBOLS = [
     "mi_scene_download_nodes", "mi_scene_download_nodes4", "mi_scene_download_prim_ids", "mi_cubemap_upload", "mi_render", "mi_render_device", "mi_shard_pixels",
     "mi_assemble_rgb8", "mi_assemble_rgb8_device", "mi_trace_primary", "mi_trace_rays", "mi_occluded_rays", "mi_last_error", "mi_abi_version",
     "mi_render_device_noalloc", "mi_noalloc_workspace_bytes",
+    "mi_group_create", "mi_group_destroy", "mi_group_size", "mi_group_scene_upload", "mi_group_scene_upload_build",
+    "mi_group_cubemap_upload", "mi_group_render",
 ]
 
 
@@ -127,6 +129,20 @@ mi.mi_scene_quality.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
 mi.mi_scene_quality.restype = C.c_int
 mi.mi_scene_download_nodes.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_int32)]
 mi.mi_scene_download_nodes.restype = C.c_int
+mi.mi_group_create.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]
+mi.mi_group_create.restype = C.c_int
+mi.mi_group_destroy.argtypes = [C.c_void_p]
+mi.mi_group_destroy.restype = None
+mi.mi_group_size.argtypes = [C.c_void_p]
+mi.mi_group_size.restype = C.c_int
+mi.mi_group_scene_upload.argtypes = [C.c_void_p, C.POINTER(SceneSoA)]
+mi.mi_group_scene_upload.restype = C.c_int
+mi.mi_group_scene_upload_build.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(BuildStats)]
+mi.mi_group_scene_upload_build.restype = C.c_int
+mi.mi_group_cubemap_upload.argtypes = [C.c_void_p, C.c_void_p]
+mi.mi_group_cubemap_upload.restype = C.c_int
+mi.mi_group_render.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.c_void_p, C.POINTER(Stats)]
+mi.mi_group_render.restype = C.c_int
 mi.mi_last_error.restype = C.c_char_p
 mi.mi_abi_version.restype = C.c_int
 
@@ -153,6 +169,8 @@ host.pt_scene_add_sphere.argtypes = [C.c_void_p, c_float_p, C.c_float, C.c_uint3
 host.pt_scene_set_camera.argtypes = [C.c_void_p, c_float_p, c_float_p, c_float_p, C.c_float, C.c_float]
 host.pt_scene_finalize.argtypes = [C.c_void_p]
 host.pt_hip_tracer_new.argtypes = [C.c_int, C.c_int, C.c_int, C.c_ulonglong]
+host.pt_hip_tracer_new_group.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_ulonglong]
+host.pt_hip_tracer_new_group.restype = C.c_void_p
 host.pt_hip_tracer_new.restype = C.c_void_p
 host.pt_tracer_free.argtypes = [C.c_void_p]
 host.pt_tracer_load_scene.argtypes = [C.c_void_p, C.c_char_p, C.c_int]

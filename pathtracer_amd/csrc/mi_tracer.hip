@@ -1399,3 +1399,212 @@ MI_API mi_status mi_cubemap_upload(mi_ctx *c, const mi_cubemap *cm) {
     c->sc.cube = c->cube.as<int32_t>();
     return MI_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// mi_group: ONE process driving several GPUs behind the Tracer interface.  One mi_ctx per device,
+// scene replicated, device k renders shard k of n (tile k mod n); the tonemapped RGBA8 tiles travel to the first
+// device over RCCL (grouped ncclSend / ncclRecv on a communicator from ncclCommInitAll: device-to-device over
+// xGMI, no host staging and no fallback), where k_assemble scatters them into the frame.  RCCL is loaded at run
+// time (dlopen) when the first group is created: single-GPU users never load it, and a host process that already
+// carries an RCCL of its own (PyTorch does) keeps using that one.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+#include <chrono>
+#include <thread>
+
+namespace {
+struct RcclApi {
+    void *lib = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+RcclApi g_rccl;
+std::mutex g_rccl_mutex;
+
+mi_status rccl_load() {
+    std::lock_guard<std::mutex> lock(g_rccl_mutex);
+    if (g_rccl.lib) return MI_OK;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    void *h = nullptr;
+    for (const char *n : names)
+        if ((h = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+    if (!h) return fail(MI_ERR_HIP, "mi_group: librccl.so not found (%s)", dlerror());
+    RcclApi a;
+    a.lib = h;
+    a.CommInitAll = (decltype(a.CommInitAll))dlsym(h, "ncclCommInitAll");
+    a.CommDestroy = (decltype(a.CommDestroy))dlsym(h, "ncclCommDestroy");
+    a.GroupStart = (decltype(a.GroupStart))dlsym(h, "ncclGroupStart");
+    a.GroupEnd = (decltype(a.GroupEnd))dlsym(h, "ncclGroupEnd");
+    a.Send = (decltype(a.Send))dlsym(h, "ncclSend");
+    a.Recv = (decltype(a.Recv))dlsym(h, "ncclRecv");
+    a.GetErrorString = (decltype(a.GetErrorString))dlsym(h, "ncclGetErrorString");
+    if (!a.CommInitAll || !a.CommDestroy || !a.GroupStart || !a.GroupEnd || !a.Send || !a.Recv || !a.GetErrorString) {
+        dlclose(h);
+        return fail(MI_ERR_HIP, "mi_group: librccl.so lacks a required symbol");
+    }
+    g_rccl = a;
+    return MI_OK;
+}
+} // namespace
+
+#define NCCLCHK(call)                                                                                              \
+    do {                                                                                                           \
+        ncclResult_t r_ = (call);                                                                                  \
+        if (r_ != ncclSuccess) return fail(MI_ERR_HIP, "%s failed: %s (%s:%d)", #call, g_rccl.GetErrorString(r_), __FILE__, __LINE__); \
+    } while (0)
+
+struct mi_group {
+    std::vector<int> devices;
+    std::vector<mi_ctx *> ctx;
+    std::vector<ncclComm_t> comms;
+    std::vector<DevBuf> rgba8;   // per device: its shard's RGBA8 tiles
+    DevBuf gathered;             // first device: every shard's tiles
+};
+
+MI_API void mi_group_destroy(mi_group *g) {
+    if (!g) return;
+    for (size_t k = 0; k < g->ctx.size(); k++) {
+        (void)hipSetDevice(g->devices[k]);
+        if (k < g->comms.size() && g->comms[k]) (void)g_rccl.CommDestroy(g->comms[k]);
+        if (k < g->rgba8.size()) g->rgba8[k].release();
+        if (k == 0) g->gathered.release();
+        mi_ctx_destroy(g->ctx[k]);
+    }
+    delete g;
+}
+
+MI_API mi_status mi_group_create(const int *device_ids, int n_dev, mi_group **out) {
+    if (!out) return fail(MI_ERR_INVALID, "mi_group_create: out is NULL");
+    *out = nullptr;
+    if (!device_ids || n_dev <= 0 || n_dev > 64) return fail(MI_ERR_INVALID, "mi_group_create: need 1..64 device ids");
+    for (int a = 0; a < n_dev; a++)
+        for (int b = a + 1; b < n_dev; b++)
+            if (device_ids[a] == device_ids[b]) return fail(MI_ERR_INVALID, "mi_group_create: device %d listed twice", device_ids[a]);
+    mi_group *g = new mi_group;
+    g->devices.assign(device_ids, device_ids + n_dev);
+    g->rgba8.resize(n_dev);
+    for (int k = 0; k < n_dev; k++) {
+        mi_ctx *c = nullptr;
+        mi_status st = mi_ctx_create(device_ids[k], &c);
+        if (st != MI_OK) { mi_group_destroy(g); return st; }
+        g->ctx.push_back(c);
+    }
+    mi_status ls = rccl_load();
+    if (ls != MI_OK) { mi_group_destroy(g); return ls; }
+    g->comms.assign(n_dev, nullptr);
+    ncclResult_t r = g_rccl.CommInitAll(g->comms.data(), n_dev, g->devices.data());
+    if (r != ncclSuccess) {
+        g->comms.clear();
+        mi_group_destroy(g);
+        return fail(MI_ERR_HIP, "ncclCommInitAll over %d device(s) failed: %s", n_dev, g_rccl.GetErrorString(r));
+    }
+    *out = g;
+    return MI_OK;
+}
+
+MI_API int mi_group_size(const mi_group *g) { return g ? (int)g->ctx.size() : 0; }
+
+MI_API mi_status mi_group_scene_upload(mi_group *g, const mi_scene_soa *scene) {
+    if (!g) return fail(MI_ERR_INVALID, "mi_group_scene_upload: group is NULL");
+    for (mi_ctx *c : g->ctx) { // replicated: the scene is read-only and small against 288 GB
+        mi_status st = mi_scene_upload(c, scene);
+        if (st != MI_OK) return st;
+    }
+    return MI_OK;
+}
+
+MI_API mi_status mi_group_scene_upload_build(mi_group *g, const mi_scene_soa *scene, const float *tri_verts, mi_build_stats *stats) {
+    if (!g) return fail(MI_ERR_INVALID, "mi_group_scene_upload_build: group is NULL");
+    for (size_t k = 0; k < g->ctx.size(); k++) { // every device builds its own copy: the builders are deterministic
+        mi_status st = mi_scene_upload_build(g->ctx[k], scene, tri_verts, k == 0 ? stats : nullptr);
+        if (st != MI_OK) return st;
+    }
+    return MI_OK;
+}
+
+MI_API mi_status mi_group_cubemap_upload(mi_group *g, const mi_cubemap *cm) {
+    if (!g) return fail(MI_ERR_INVALID, "mi_group_cubemap_upload: group is NULL");
+    for (mi_ctx *c : g->ctx) {
+        mi_status st = mi_cubemap_upload(c, cm);
+        if (st != MI_OK) return st;
+    }
+    return MI_OK;
+}
+
+MI_API mi_status mi_group_render(mi_group *g, const mi_render_params *p, uint8_t *rgb8_out, mi_stats *stats) {
+    if (!g || !p || !rgb8_out) return fail(MI_ERR_INVALID, "mi_group_render: NULL argument");
+    if (p->shard_count > 1) return fail(MI_ERR_INVALID, "mi_group_render: the group shards the frame itself (shard_count must be 0 or 1)");
+    const int n = (int)g->ctx.size();
+    const auto t0 = std::chrono::steady_clock::now();
+    mi_render_params p0 = *p;
+    p0.shard_rank = 0;
+    p0.shard_count = n;
+    const int64_t stride = mi_shard_pixels(&p0); // shard 0 owns the most tiles
+    if (stride < 0) return MI_ERR_INVALID;      // make_geom has set the message
+    // every device renders its shard on a host thread of its own (mi_render_device blocks until its stream is done)
+    std::vector<mi_status> st(n, MI_OK);
+    std::vector<std::string> err(n);
+    std::vector<mi_stats> ds(n);
+    for (int k = 0; k < n; k++) {
+        HIPCHK(hipSetDevice(g->devices[k]));
+        HIPCHK(g->rgba8[k].ensure(std::max<size_t>((size_t)stride * 4, 16)));
+    }
+    HIPCHK(hipSetDevice(g->devices[0]));
+    HIPCHK(g->gathered.ensure(std::max<size_t>((size_t)stride * 4 * n, 16)));
+    {
+        std::vector<std::thread> th;
+        for (int k = 0; k < n; k++)
+            th.emplace_back([&, k] {
+                mi_render_params pk = *p;
+                pk.shard_rank = k;
+                pk.shard_count = n;
+                st[k] = mi_render_device(g->ctx[k], &pk, nullptr, g->rgba8[k].p, nullptr, &ds[k]);
+                if (st[k] != MI_OK) err[k] = mi_last_error(); // the message is per thread
+            });
+        for (auto &t : th) t.join();
+    }
+    for (int k = 0; k < n; k++)
+        if (st[k] != MI_OK) return fail(st[k], "mi_group_render: device %d: %s", g->devices[k], err[k].c_str());
+    // exchange: RGBA8 tiles of shards 1..n-1 -> first device, one grouped send/recv pair per shard; shard 0 is already there
+    const size_t bytes = (size_t)stride * 4;
+    const auto t1 = std::chrono::steady_clock::now();
+    HIPCHK(hipSetDevice(g->devices[0]));
+    HIPCHK(hipMemcpyAsync(g->gathered.p, g->rgba8[0].p, bytes, hipMemcpyDeviceToDevice, g->ctx[0]->stream));
+    NCCLCHK(g_rccl.GroupStart());
+    for (int k = 1; k < n; k++) {
+        HIPCHK(hipSetDevice(g->devices[k]));
+        NCCLCHK(g_rccl.Send(g->rgba8[k].p, bytes, ncclUint8, 0, g->comms[k], g->ctx[k]->stream));
+        HIPCHK(hipSetDevice(g->devices[0]));
+        NCCLCHK(g_rccl.Recv((char *)g->gathered.p + (size_t)k * bytes, bytes, ncclUint8, k, g->comms[0], g->ctx[0]->stream));
+    }
+    NCCLCHK(g_rccl.GroupEnd());
+    for (int k = 1; k < n; k++) { // the senders' buffers are free again when their streams are done
+        HIPCHK(hipSetDevice(g->devices[k]));
+        HIPCHK(hipStreamSynchronize(g->ctx[k]->stream));
+    }
+    HIPCHK(hipSetDevice(g->devices[0]));
+    HIPCHK(hipStreamSynchronize(g->ctx[0]->stream));
+    const auto t2 = std::chrono::steady_clock::now();
+    mi_status as = mi_assemble_rgb8(g->ctx[0], &p0, g->gathered.p, stride, rgb8_out);
+    if (as != MI_OK) return as;
+    const auto t3 = std::chrono::steady_clock::now();
+    if (stats) {
+        memset(stats, 0, sizeof *stats);
+        for (int k = 0; k < n; k++) {
+            stats->rays_cast += ds[k].rays_cast; stats->paths += ds[k].paths; stats->rays_extend += ds[k].rays_extend;
+            stats->extend_launches += ds[k].extend_launches; stats->batches += ds[k].batches;
+            stats->ms_extend = std::max(stats->ms_extend, ds[k].ms_extend); // of the slowest device
+            stats->ms_shade = std::max(stats->ms_shade, ds[k].ms_shade);
+            stats->ms_tail = std::max(stats->ms_tail, ds[k].ms_tail);
+        }
+        auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        stats->ms_total = ms(t0, t3);                      // wall clock of the whole call, exchange and copy to the host included
+        stats->ms_other = ms(t1, t2) + ms(t2, t3);         // exchange + assembly
+    }
+    return MI_OK;
+}

@@ -70,6 +70,13 @@ PT_API pt::HipTracer *pt_hip_tracer_new(int depth, int samples, int device, unsi
     if (!t->ok()) { g_err = t->error(); delete t; return nullptr; }
     return t;
 }
+PT_API pt::HipTracer *pt_hip_tracer_new_group(int depth, int samples, int first_device, int n_devices, unsigned long long seed) {
+    pt::TraceOptions o;
+    o.depth = depth; o.samples = samples; o.device = first_device; o.n_devices = n_devices; o.seed = seed;
+    auto *t = new pt::HipTracer(o);
+    if (!t->ok()) { g_err = t->error(); delete t; return nullptr; }
+    return t;
+}
 PT_API void pt_tracer_free(pt::HipTracer *t) { delete t; }
 PT_API int pt_tracer_load_cubemap(pt::HipTracer *t, const char *one_face_file) { return t->loadCubemap(one_face_file) ? 1 : 0; }
 // matchCubemapFiles for tests: 1 and the six names joined by '\n' in out (NUL terminated) on success

@@ -5,7 +5,8 @@
 // (CUDA threads per block) is accepted and ignored, -j is accepted and ignored (JSON
 // overrides are outside this backend's scope), -c <one of the six face files> loads the
 // cubemap background (CommandLineUI.cu:40-42,66-68).
-// Added: -G <device>, -S <seed>, -B (build the BVH on the GPU).
+// Added: -G <device>, -N <GPUs> (devices -G .. -G + N - 1 render tile shards of the frame in one process, tiles gathered
+// over RCCL), -S <seed>, -B (build the BVH on the GPU).
 #include <unistd.h>
 
 #include <cmath>
@@ -20,13 +21,14 @@ int main(int argc, char **argv) {
     int size = 512; // TraceUI.h:55
     std::string cubemap;
     int c;
-    while ((c = getopt(argc, argv, "t:r:w:hj:c:s:gq:G:S:B")) != -1) {
+    while ((c = getopt(argc, argv, "t:r:w:hj:c:s:gq:G:N:S:B")) != -1) {
         switch (c) {
             case 't': o.threads = atoi(optarg); // falls through into -r, CommandLineUI.cu:29-33
             case 'r': o.depth = atoi(optarg); break;
             case 'w': size = atoi(optarg); break;
             case 's': o.samples = atoi(optarg); break;
             case 'G': o.device = atoi(optarg); break;
+            case 'N': o.n_devices = atoi(optarg); break;
             case 'S': o.seed = strtoull(optarg, nullptr, 10); break;
             case 'B': o.device_bvh = true; break;
             case 'c': cubemap = optarg; break;   // CommandLineUI.cu:40-42
@@ -34,7 +36,7 @@ int main(int argc, char **argv) {
             default:
                 std::cerr << "usage: " << argv[0] << " [options] [input.ray output.png]\n"
                           << "  -r <#>  recursion level (default 0)\n  -w <#>  image width (default 512)\n"
-                          << "  -s <#>  samples per dimension (default 2)\n  -G <#>  HIP device\n  -S <#>  RNG seed\n  -B      build the BVH on the GPU (LBVH)\n";
+                          << "  -s <#>  samples per dimension (default 2)\n  -G <#>  HIP device\n  -N <#>  number of GPUs (starting at -G), one process, tiles gathered over RCCL\n  -S <#>  RNG seed\n  -B      build the BVH on the GPU (PLOC)\n";
                 return 1;
         }
     }

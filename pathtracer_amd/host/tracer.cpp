@@ -114,7 +114,13 @@ bool Tracer::loadCubemap(const char *oneFaceFile) { // TraceUI.cu:150-169
 
 // ------------------------------------------------------------------ HipTracer
 HipTracer::HipTracer(const TraceOptions &o) : Tracer(o), opts_(o) {
-    status_ = mi_ctx_create(o.device, &ctx_);
+    if (o.n_devices > 0) {
+        std::vector<int> ids;
+        for (int k = 0; k < o.n_devices; k++) ids.push_back(o.device + k);
+        status_ = mi_group_create(ids.data(), o.n_devices, &group_);
+    } else {
+        status_ = mi_ctx_create(o.device, &ctx_);
+    }
     if (status_ != MI_OK) {
         error_ = mi_last_error();
         std::cerr << "HipTracer: " << error_ << std::endl;
@@ -124,13 +130,14 @@ HipTracer::HipTracer(const TraceOptions &o) : Tracer(o), opts_(o) {
 HipTracer::~HipTracer() {
     if (worker_.joinable()) worker_.join();
     if (ctx_) mi_ctx_destroy(ctx_);
+    if (group_) mi_group_destroy(group_);
 }
 
 bool HipTracer::cubemapLoaded() {
-    if (!ctx_) return false;
+    if (!ctx_ && !group_) return false;
     mi_cubemap cm;
     for (int i = 0; i < 6; i++) { cm.width[i] = cube_[i].w; cm.height[i] = cube_[i].h; cm.rgb[i] = cube_[i].rgb.data(); }
-    status_ = mi_cubemap_upload(ctx_, &cm);
+    status_ = group_ ? mi_group_cubemap_upload(group_, &cm) : mi_cubemap_upload(ctx_, &cm);
     if (status_ != MI_OK) {
         error_ = mi_last_error();
         std::cerr << "HipTracer: " << error_ << std::endl;
@@ -140,7 +147,7 @@ bool HipTracer::cubemapLoaded() {
 }
 
 bool HipTracer::sceneLoaded() { // upload replaces Scene::clone, GpuTracer.cu:172-175
-    if (!ctx_) return false;
+    if (!ctx_ && !group_) return false;
     if (opts_.device_bvh) { // slot vertices are kept as 3 float4 per triangle; the ABI takes 9 floats
         const std::vector<float> &v4 = scene->slotVertices();
         std::vector<float> v3(v4.size() / 12 * 9);
@@ -148,9 +155,10 @@ bool HipTracer::sceneLoaded() { // upload replaces Scene::clone, GpuTracer.cu:17
             for (int k = 0; k < 3; k++)
                 for (int a = 0; a < 3; a++) v3[9 * t + 3 * k + a] = v4[12 * t + 4 * k + a];
         mi_build_stats bs;
-        status_ = mi_scene_upload_build(ctx_, &scene->soa(), v3.empty() ? nullptr : v3.data(), &bs);
+        status_ = group_ ? mi_group_scene_upload_build(group_, &scene->soa(), v3.empty() ? nullptr : v3.data(), &bs)
+                         : mi_scene_upload_build(ctx_, &scene->soa(), v3.empty() ? nullptr : v3.data(), &bs);
     } else {
-        status_ = mi_scene_upload(ctx_, &scene->soa());
+        status_ = group_ ? mi_group_scene_upload(group_, &scene->soa()) : mi_scene_upload(ctx_, &scene->soa());
     }
     if (status_ != MI_OK) {
         error_ = mi_last_error();
@@ -163,13 +171,13 @@ bool HipTracer::sceneLoaded() { // upload replaces Scene::clone, GpuTracer.cu:17
 void HipTracer::traceImage(int w, int h) { // GpuTracer.cu:161-189
     if (worker_.joinable()) worker_.join();
     worker_ = std::thread([this, w, h] {
-        if (!ctx_) { status_ = MI_ERR_NO_DEVICE; return; }
+        if (!ctx_ && !group_) { status_ = MI_ERR_NO_DEVICE; return; }
         mi_render_params p{};
         p.width = w; p.height = h;
         p.samples_per_dim = (int)samples;
         p.depth = (int)depth;
         p.seed = opts_.seed;
-        status_ = mi_render(ctx_, &p, nullptr, buffer.data(), &stats_);
+        status_ = group_ ? mi_group_render(group_, &p, buffer.data(), &stats_) : mi_render(ctx_, &p, nullptr, buffer.data(), &stats_);
         if (status_ != MI_OK) {
             error_ = mi_last_error();
             std::cerr << "HipTracer: " << error_ << std::endl;

@@ -21,7 +21,9 @@ struct TraceOptions {
     int depth = 0;          // -r, TraceUI.h:56 default 0
     int samples = 2;        // -s, per dimension, TraceUI.h:59 default 2
     int threads = 0;        // -t (CPU backends only)
-    int device = 0;         // HIP device of the MI355X backend
+    int device = 0;         // HIP device of the MI355X backend (the first one of a group)
+    int n_devices = 0;      // > 0: devices device .. device + n_devices - 1 as one mi_group (frame sharded by tile, RGBA8
+                            // tiles gathered over RCCL); 0: one context on `device`
     unsigned long long seed = 0;
     bool device_bvh = false; // build the BVH on the GPU (mi_scene_upload_build) instead of uploading the host-built one
 };
@@ -79,6 +81,7 @@ protected:
 private:
     TraceOptions opts_;
     mi_ctx *ctx_ = nullptr;
+    mi_group *group_ = nullptr;   // instead of ctx_ when opts_.n_devices > 0
     std::thread worker_;
     mi_stats stats_{};
     mi_status status_ = MI_OK;

@@ -154,6 +154,56 @@ class Context:
         return out
 
 
+class Group:
+    """One ``mi_group``: several GPUs in one process (scene replicated, frame sharded by tile, RGBA8 tiles gathered to
+    the first device over RCCL)."""
+
+    def __init__(self, devices=(0,)):
+        ids = (C.c_int * len(devices))(*devices)
+        h = C.c_void_p()
+        N.check(N.mi.mi_group_create(ids, len(devices), C.byref(h)))
+        self._h = h
+        self.scene = None
+
+    def close(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and N is not None and getattr(N, "mi", None) is not None:
+            N.mi.mi_group_destroy(h)
+
+    __del__ = close
+
+    def __len__(self):
+        return N.mi.mi_group_size(self._h)
+
+    def upload(self, scene):
+        N.check(N.mi.mi_group_scene_upload(self._h, scene.soa))
+        self.scene = scene
+
+    def upload_build(self, scene):
+        verts = np.ascontiguousarray(scene.slot_vertices()[:, :, :3], np.float32)
+        st = N.BuildStats()
+        N.check(N.mi.mi_group_scene_upload_build(self._h, scene.soa, verts.ctypes.data if len(verts) else None, C.byref(st)))
+        self.scene = scene
+        return st
+
+    def set_cubemap(self, faces):
+        if faces is None:
+            N.check(N.mi.mi_group_cubemap_upload(self._h, None))
+            return
+        faces = [np.ascontiguousarray(f, np.uint8) for f in faces]
+        cm = N.CubeMap()
+        for i, f in enumerate(faces):
+            cm.width[i], cm.height[i], cm.rgb[i] = f.shape[1], f.shape[0], f.ctypes.data
+        N.check(N.mi.mi_group_cubemap_upload(self._h, C.byref(cm)))
+
+    def render(self, params):
+        """(rgb8 uint8[h,w,3], Stats); row 0 is the bottom row."""
+        rgb = np.zeros((params.height, params.width, 3), np.uint8)
+        st = N.Stats()
+        N.check(N.mi.mi_group_render(self._h, C.byref(params), rgb.ctypes.data, C.byref(st)))
+        return rgb, st
+
+
 def shard_pixels(params):
     return N.mi.mi_shard_pixels(C.byref(params))
 
@@ -161,8 +211,10 @@ def shard_pixels(params):
 class HipTracer:
     """The Tracer-shaped object (C++ class pt::HipTracer in pathtracer_amd/host/tracer.h)."""
 
-    def __init__(self, depth=0, samples=2, device=0, seed=0):
-        h = N.host.pt_hip_tracer_new(depth, samples, device, seed)
+    def __init__(self, depth=0, samples=2, device=0, seed=0, n_devices=0):
+        """n_devices > 0: the devices device .. device + n_devices - 1 as one mi_group (`ray -N`)."""
+        h = (N.host.pt_hip_tracer_new_group(depth, samples, device, n_devices, seed) if n_devices > 0
+             else N.host.pt_hip_tracer_new(depth, samples, device, seed))
         if not h:
             raise N.MiError(N.MI_ERR_NO_DEVICE, N.host.pt_last_error().decode())
         self._h = C.c_void_p(h)

@@ -68,6 +68,14 @@ def test_without_a_device_everything_fails_loudly():
     assert e.value.status == N.MI_ERR_NO_DEVICE and "HIP device" in str(e.value)
     with pytest.raises(P.MiError):
         P.HipTracer()
+    with pytest.raises(P.MiError) as e:
+        P.Group([0])                      # no device: the group fails like the context, before RCCL is touched
+    assert e.value.status == N.MI_ERR_NO_DEVICE
+    with pytest.raises(P.MiError):
+        P.HipTracer(n_devices=2)
+    assert N.mi.mi_group_create(None, 0, None) == N.MI_ERR_INVALID
+    assert N.mi.mi_group_render(None, None, None, None) == N.MI_ERR_INVALID
+    assert N.mi.mi_render_device_noalloc(None, None, None, None, None, None) == N.MI_ERR_INVALID
     assert N.mi.mi_scene_upload(None, None) == N.MI_ERR_INVALID
     assert N.mi.mi_render(None, None, None, None, None) == N.MI_ERR_INVALID
     assert b"NULL" in N.mi.mi_last_error()
