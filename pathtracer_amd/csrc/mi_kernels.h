@@ -1,13 +1,16 @@
 // mi_kernels.h — hand-written HIP kernels of the wavefront path tracer (gfx950).
 //
-// Stages (one launch each per bounce level; all paths of a batch are at the same
-// level k in iteration k):
-//   k_generate : camera rays for a batch of (pixel, sample) slots   [camera.cu:6-16, CpuTracer.cu:99-109]
-//   k_extend   : BVH closest hit, LDS short stack, per-wave dynamic  [bvh.cu:3-10,178-207, bbox.cu:15-34,
-//                work fetch                                           trimesh.cu:87-121, sphere.cu:5-35]
-//   k_shade    : material branch, next ray, termination, wave-ballot [CpuTracer.cu:119-186, :37-53]
-//                compaction of survivors into the next queue
-//   k_resolve  : per-pixel mean in fixed sample order + Hable tonemap [CpuTracer.cu:108, tracer.cu:20-30,95-100]
+// Kernels (per bounce level k of a batch: k_tail | k_extend | k_shade; all paths of a batch are at level k):
+//   k_extend   : BVH closest hit (any-hit variant for occlusion queries) of every ray of   [bvh.cu:3-10,178-207, bbox.cu:15-34,
+//                the level's stream: persistent waves, per-lane state machine over a       trimesh.cu:87-121, sphere.cu:5-35]
+//                quantised 4-wide tree, LDS short stack + LDS treelet, static chunk deal;
+//                level 0 computes the camera rays itself (there is no generate kernel)     [camera.cu:6-16, CpuTracer.cu:99-109]
+//   k_shade    : material branch, next ray, termination + history fold, wave-ballot        [CpuTracer.cu:119-186, :37-53]
+//                compaction of the survivors into the next level's ray stream
+//   k_tail     : once a level holds few rays, ONE launch carries every remaining path
+//                through all its remaining levels (traverse -> shade -> traverse ... per lane)
+//   k_resolve  : per-pixel mean in fixed sample order + Hable tonemap                       [CpuTracer.cu:108, tracer.cu:20-30,95-100]
+//   k_assemble, k_unpermute_mean : shard-local outputs -> frame order
 //
 // Numerics contract: fp32, no FMA contraction (-ffp-contract=off),
 // IEEE divide/sqrt, operations in the order of the cited reference lines, so the
@@ -606,18 +609,18 @@ __device__ __forceinline__ void leaf_phase(const DevScene &sc, Lane &L, lds_int 
 
 // Persistent waves, per-lane ray refill, and leaf tests postponed to their own phase.
 //
-// Every lane runs a small state machine: `cur` = next interior node (MI_DONE when the
-// stack is empty), `pend0/pend1` = leaf primitives found but not yet tested.  In each
-// iteration the WAVE executes one of two code blocks:
-//   node phase — lanes without pending leaves fetch their node (64 B), slab-test both
-//                child boxes, queue leaf children as pending, descend near-first / pop;
-//   leaf phase — lanes with a pending leaf test one primitive (the only place the
-//                triangle/sphere code exists).
-// The leaf phase runs when at least `leaf_min` lanes wait for it (or nobody can do node
-// work), so the expensive primitive test executes with many lanes active instead of
-// once per node step for the few lanes that happen to have reached a leaf.  Postponing
-// a leaf test never changes the result: the closest hit is order independent (tie rule
-// above); only the culling distance h.t is momentarily stale.
+// Every lane runs a small state machine over ONE ref, `cur`: >= 0 a 4-wide node to visit, < 0 a leaf (~slot) to
+// test, MI_DONE when its stack is empty.  Leaves travel through the same LDS stack as nodes.  In each iteration
+// the WAVE executes one of two code blocks:
+//   node phase — lanes whose ref is a node fetch it (64 B: four child boxes as 16-bit plane codes + four refs),
+//                slab-test the four boxes, continue with the nearest child that is hit and push the others;
+//   leaf phase — lanes whose ref is a leaf test that one primitive (the only place the triangle/sphere code
+//                exists) and pop.
+// The leaf phase runs when at least `leaf_min` lanes wait for it (or nobody can do node work), so the expensive
+// primitive test executes with many lanes active instead of once per node step for the few lanes that happen to
+// have reached a leaf.  A wave that has nothing left to refill with (draining) runs merged_step instead: both
+// kinds in one step with one fetch.  Postponing a leaf test never changes the result: the closest hit is order
+// independent (tie rule above); only the culling distance h.t is momentarily stale.
 //
 // Work distribution and refill: see the comments in the kernel body.  Every wave leaves
 // through the same exit (work exhausted and no lane active).
