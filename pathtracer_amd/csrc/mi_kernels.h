@@ -41,6 +41,10 @@ struct DevScene {
     const float4 *tri_normal;
     const uint32_t *tri_mat; // 3 per triangle
     const uint8_t *tri_has_vmat;
+    // What shading reads of a triangle in ONE 32-B record (k_pack_shade makes it from the three arrays above, which
+    // stay the source for the device builder's permutation): (normal.xyz, hasMaterials), (material id a, b, c, 0)
+    const uint4 *tri_shade;
+    uint32_t n_mat;
     const float4 *sph; // (cx, cy, cz, r)
     const uint32_t *sph_mat;
     const float4 *mats; // 5 x float4 per material
@@ -796,22 +800,43 @@ struct DMat {
     float4 ke, kd, kr, kt;
     float index;
 };
-__device__ __forceinline__ DMat load_mat(const DevScene &sc, uint32_t id) {
+// The material table in LDS when it is small (it nearly always is: a handful of materials, 80 B each): the fetch
+// of a hit's material is then no second dependent trip to global memory behind the triangle's record.
+#define MI_LDS_MATS 48
+typedef float mi_v4f __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) mi_v4f lds_float4; // a plain vector type: HIP's float4 class does not copy out of an address space
+struct MatTable {
+    const lds_float4 *lds; // the table's copy in LDS, used when `in_lds`
+    bool in_lds;           // wave-uniform
+};
+__device__ __forceinline__ MatTable mat_table_load(const DevScene &sc, float4 *lds_mats) { // every thread of the workgroup; contains a barrier
+    const bool in_lds = sc.n_mat <= MI_LDS_MATS;
+    if (in_lds) for (uint32_t i = threadIdx.x; i < 5u * sc.n_mat; i += MI_BLOCK) lds_mats[i] = sc.mats[i];
+    __syncthreads();
+    return MatTable{(const lds_float4 *)lds_mats, in_lds};
+}
+__device__ __forceinline__ DMat load_mat(const DevScene &sc, const MatTable &mt, uint32_t id) {
+    if (mt.in_lds) {
+        const lds_float4 *m = mt.lds + 5 * id;
+        const mi_v4f a = m[0], b = m[1], c = m[2], d = m[3], e = m[4];
+        return DMat{make_float4(a.x, a.y, a.z, a.w), make_float4(b.x, b.y, b.z, b.w), make_float4(c.x, c.y, c.z, c.w), make_float4(d.x, d.y, d.z, d.w), e.x};
+    }
     const float4 *m = sc.mats + 5 * (size_t)id;
     return DMat{m[0], m[1], m[2], m[3], m[4].x};
 }
 
 // Geometric normal and material at a hit (trimesh.cu:107-119, sphere.cu:23-32).
-__device__ __forceinline__ void hit_surface(const DevScene &sc, int slot, float t, f3 o, f3 d, f3 &N, DMat &m) {
+__device__ __forceinline__ void hit_surface(const DevScene &sc, const MatTable &mt, int slot, float t, f3 o, f3 d, f3 &N, DMat &m) {
     if ((uint32_t)slot >= sc.n_tri) {
         int k = slot - (int)sc.n_tri;
         float4 cr = sc.sph[k];
         N = normalize3((o + (t * d)) - xyz(cr)); // ray.h:67, sphere.cu:26,31
-        m = load_mat(sc, sc.sph_mat[k]);
+        m = load_mat(sc, mt, sc.sph_mat[k]);
     } else {
-        N = xyz(sc.tri_normal[slot]);
-        const uint32_t *mid = sc.tri_mat + 3 * (size_t)slot;
-        if (sc.tri_has_vmat[slot]) { // trimesh.cu:110-116 with material.h:91-100,137-146
+        const uint4 s0 = sc.tri_shade[2 * (size_t)slot], s1 = sc.tri_shade[2 * (size_t)slot + 1];
+        N = mk3(__uint_as_float(s0.x), __uint_as_float(s0.y), __uint_as_float(s0.z));
+        const uint32_t mid[3] = {s1.x, s1.y, s1.z};
+        if (s0.w) { // trimesh.cu:110-116 with material.h:91-100,137-146
             // u, v of trimesh.cu:98-101 again, from the accepted t: the operations of tri_test on the same inputs
             const char *rec = (const char *)sc.tri + ((uint32_t)slot << 6);
             const float4 v0 = *(const float4 *)(rec), ui = *(const float4 *)(rec + 16), vi = *(const float4 *)(rec + 32);
@@ -821,18 +846,18 @@ __device__ __forceinline__ void hit_surface(const DevScene &sc, int slot, float 
             // (a*w + b*u) + c*v, accumulated one vertex material at a time (same
             // association, a third of the registers of loading all three first)
             const float wt[3] = {w, u, v};
-            DMat a = load_mat(sc, mid[0]);
+            DMat a = load_mat(sc, mt, mid[0]);
             m.ke = mul4(a.ke, w); m.kd = mul4(a.kd, w); m.kr = mul4(a.kr, w); m.kt = mul4(a.kt, w);
             m.index = a.index * w;
 #pragma unroll 1
             for (int k = 1; k < 3; k++) {
-                DMat b = load_mat(sc, mid[k]);
+                DMat b = load_mat(sc, mt, mid[k]);
                 m.ke = add4(m.ke, mul4(b.ke, wt[k])); m.kd = add4(m.kd, mul4(b.kd, wt[k]));
                 m.kr = add4(m.kr, mul4(b.kr, wt[k])); m.kt = add4(m.kt, mul4(b.kt, wt[k]));
                 m.index = m.index + b.index * wt[k];
             }
         } else {
-            m = load_mat(sc, mid[0]);
+            m = load_mat(sc, mt, mid[0]);
         }
     }
 }
@@ -922,7 +947,7 @@ __device__ __forceinline__ uint64_t path_id(const ShardGeom &g, int px, int py, 
 // is folded from the stored history and written to path_out — and false is returned,
 // or (e, w) of this level are stored and the continuation ray (no, nd) with throughput
 // Tn is returned with true.
-__device__ __forceinline__ bool shade_path(const DevScene &sc, uint64_t seed, uint64_t path, int level, int depth_left, uint32_t slot,
+__device__ __forceinline__ bool shade_path(const DevScene &sc, const MatTable &mt, uint64_t seed, uint64_t path, int level, int depth_left, uint32_t slot,
                                            f3 o, f3 d, float4 T, float t, int pslot, float4 *hist,
                                            size_t cap, size_t e_off, uint32_t &emask, float4 *path_out, f3 &no, f3 &nd, float4 &Tn) {
     if (pslot < 0) { // CpuTracer.cu:124-125: miss -> cubemap colour, or (1,1,1,1) without a cubemap
@@ -932,7 +957,7 @@ __device__ __forceinline__ bool shade_path(const DevScene &sc, uint64_t seed, ui
     }
     f3 N;
     DMat m;
-    hit_surface(sc, pslot, t, o, d, N, m);
+    hit_surface(sc, mt, pslot, t, o, d, N, m);
     float4 e = mul4(m.ke, 32.0f); // CpuTracer.cu:131,185
     if (depth_left < 0) {         // CpuTracer.cu:130-131
         path_out[slot] = clamp01_4(fold_history(hist, cap, e_off, slot, level, emask, e));
@@ -1000,6 +1025,8 @@ k_shade(DevScene sc, ShardGeom g, uint32_t pix0, uint32_t npix, FastDiv d_npix, 
         const uint32_t *count_ptr, const float2 *hits, float4 *hist, size_t cap, size_t e_off, float4 *path_out, RayStream out,
         uint32_t *next_count, uint32_t n_fixed, const uint32_t *tail_level) {
     if (!PRIMARY && tail_took_over(tail_level, level)) return;
+    __shared__ float4 lds_mats[5 * MI_LDS_MATS];
+    const MatTable mt = mat_table_load(sc, lds_mats);
     // i runs over the virtual positions (64 per virtual chunk) of the input stream
     const uint32_t n_virtual = stream_chunks(PRIMARY ? nullptr : count_ptr, n_fixed) << 6;
     const uint32_t stride = gridDim.x * MI_BLOCK;
@@ -1065,7 +1092,7 @@ k_shade(DevScene sc, ShardGeom g, uint32_t pix0, uint32_t npix, FastDiv d_npix, 
         float4 Tn = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         uint32_t emask = PRIMARY ? 0u : __float_as_uint(cur.d4.w); // which earlier levels stored an emission term
         if (live) {
-            alive = shade_path(sc, seed, path_id(g, px, py, samp), level, depth_left, slot, o, d, T, cur.h2.x, __float_as_int(cur.h2.y),
+            alive = shade_path(sc, mt, seed, path_id(g, px, py, samp), level, depth_left, slot, o, d, T, cur.h2.x, __float_as_int(cur.h2.y),
                                hist, cap, e_off, emask, path_out, no, nd, Tn);
         }
         const uint32_t pos = out_base + queue_reserve(alive, my_count);
@@ -1099,6 +1126,8 @@ k_tail(DevScene sc, ShardGeom g, uint32_t pix0, uint32_t npix, FastDiv d_npix, i
     for (int i = threadIdx.x; i < sc.treelet_count * 4; i += MI_BLOCK) lds_treelet[i] = sc.qnodes[(size_t)sc.treelet_base * 4 + i];
     __syncthreads();
     const NodeBase nbase = node_base(sc, lds_treelet);
+    __shared__ float4 lds_mats[5 * MI_LDS_MATS];
+    const MatTable mt = mat_table_load(sc, lds_mats);
     const int lane = threadIdx.x & 63;
     if (blockIdx.x == 0 && threadIdx.x == 0) *tail_level = (uint32_t)level0;
     lds_int *stack = (lds_int *)lds_stack + threadIdx.x;
@@ -1164,7 +1193,7 @@ k_tail(DevScene sc, ShardGeom g, uint32_t pix0, uint32_t npix, FastDiv d_npix, i
                 local_to_pixel(g, slot_to_local(g, pix0 + lp), px, py);
                 f3 no, nd;
                 float4 Tn;
-                cont = shade_path(sc, seed, path_id(g, px, py, samp), level, depth_total - level, slot, L.o, L.d, T, L.h.t, L.h.slot,
+                cont = shade_path(sc, mt, seed, path_id(g, px, py, samp), level, depth_total - level, slot, L.o, L.d, T, L.h.t, L.h.slot,
                                   hist, cap, e_off, emask, path_out, no, nd, Tn);
                 if (cont) {
                     T = Tn;
@@ -1215,6 +1244,16 @@ k_resolve(ShardGeom g, uint32_t pix0, uint32_t npix, const float4 *path_out, flo
     }
 }
 
+// DevScene::tri_shade from the three per-triangle arrays shading used to gather separately.
+__global__ void __launch_bounds__(MI_BLOCK)
+k_pack_shade(uint32_t n_tri, const float4 *tri_normal, const uint32_t *tri_mat, const uint8_t *tri_has_vmat, uint4 *out) {
+    const uint32_t i = blockIdx.x * MI_BLOCK + threadIdx.x;
+    if (i >= n_tri) return;
+    const float4 n = tri_normal[i];
+    out[2 * (size_t)i] = make_uint4(__float_as_uint(n.x), __float_as_uint(n.y), __float_as_uint(n.z), tri_has_vmat[i] ? 1u : 0u);
+    out[2 * (size_t)i + 1] = make_uint4(tri_mat[3 * (size_t)i], tri_mat[3 * (size_t)i + 1], tri_mat[3 * (size_t)i + 2], 0u);
+}
+
 // Probe output for mi_trace_primary / mi_trace_rays.
 __global__ void __launch_bounds__(MI_BLOCK)
 k_probe_out(DevScene sc, int64_t n, const float4 *ray_o, const float4 *ray_d, const float2 *hits, int32_t *prim_id, float *t_out, float *n_out) {
@@ -1228,7 +1267,7 @@ k_probe_out(DevScene sc, int64_t n, const float4 *ray_o, const float4 *ray_d, co
         f3 N = mk3(0, 0, 0);
         if (slot >= 0) {
             DMat m;
-            hit_surface(sc, slot, h.x, xyz(ray_o[i]), xyz(ray_d[i]), N, m);
+            hit_surface(sc, MatTable{nullptr, false}, slot, h.x, xyz(ray_o[i]), xyz(ray_d[i]), N, m);
         }
         n_out[3 * i] = N.x; n_out[3 * i + 1] = N.y; n_out[3 * i + 2] = N.z;
     }

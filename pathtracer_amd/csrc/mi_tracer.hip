@@ -90,7 +90,7 @@ struct mi_ctx {
     DevScene sc{};
     uint32_t n_nodes = 0;   // of the binary tree kept in `nodes` (download, quality); the kernels walk `nodes4`
     int32_t root_ref2 = ~0;
-    DevBuf nodes, nodes4, qnodes, tri, tri_normal, tri_mat, tri_has_vmat, sph, sph_mat, mats, prim_id, cube;
+    DevBuf nodes, nodes4, qnodes, tri, tri_normal, tri_mat, tri_has_vmat, tri_shade, sph, sph_mat, mats, prim_id, cube;
     // per-batch path state (sized by slot capacity / depth): two ray streams (level k reads
     // stream k&1 and writes stream (k+1)&1), hits by stream position, history and path value by slot
     // Two sets: the batches of a frame alternate between two streams (`streams` below), each with its own state.
@@ -220,7 +220,7 @@ MI_API void mi_ctx_destroy(mi_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    DevBuf *all[] = {&c->nodes, &c->nodes4, &c->qnodes, &c->tri, &c->tri_normal, &c->tri_mat, &c->tri_has_vmat, &c->sph, &c->sph_mat, &c->mats,
+    DevBuf *all[] = {&c->nodes, &c->nodes4, &c->qnodes, &c->tri, &c->tri_normal, &c->tri_mat, &c->tri_has_vmat, &c->tri_shade, &c->sph, &c->sph_mat, &c->mats,
                      &c->prim_id, &c->cube, &c->out_mean, &c->out_rgba8,
                      &c->out_rgb8, &c->out_mean_frame, &c->probe_i, &c->probe_t, &c->probe_n};
     for (auto &pb : c->pb) {
@@ -404,6 +404,7 @@ static mi_status upload_prims(mi_ctx *c, const mi_scene_soa *s) {
     d.prim_id = c->prim_id.as<int32_t>();
     d.n_tri = s->n_tri;
     d.n_sph = s->n_sph;
+    d.n_mat = s->n_mat;
     d.eye = make_float4(s->cam_eye[0], s->cam_eye[1], s->cam_eye[2], s->cam_eye[3]);
     d.u = make_float4(s->cam_u[0], s->cam_u[1], s->cam_u[2], s->cam_u[3]);
     d.v = make_float4(s->cam_v[0], s->cam_v[1], s->cam_v[2], s->cam_v[3]);
@@ -411,10 +412,26 @@ static mi_status upload_prims(mi_ctx *c, const mi_scene_soa *s) {
     return MI_OK;
 }
 
+// The 32-B shading records (DevScene::tri_shade) from the per-triangle arrays as they stand on the device — after
+// the device builder's permutation when there was one.
+static mi_status pack_shade(mi_ctx *c) {
+    const uint32_t nt = c->sc.n_tri;
+    HIPCHK(c->tri_shade.ensure(std::max<size_t>((size_t)nt * 32, 16)));
+    if (nt)
+        hipLaunchKernelGGL(k_pack_shade, dim3((nt + MI_BLOCK - 1) / MI_BLOCK), dim3(MI_BLOCK), 0, c->stream, nt, c->tri_normal.as<float4>(),
+                           c->tri_mat.as<uint32_t>(), c->tri_has_vmat.as<uint8_t>(), c->tri_shade.as<uint4>());
+    HIPCHK(hipGetLastError());
+    c->sc.tri_shade = c->tri_shade.as<uint4>();
+    return MI_OK; // quantize_nodes4 synchronises the stream
+}
+
 // Last step of every upload: the fp32 4-wide nodes in c->nodes4 (the tree and the treelet copies behind
 // it, n_total nodes, root c->sc.root_ref) -> the 64-B quantised nodes the kernels read.  The code grid
 // spans the root's box (the union of its seats): F = 0.51 at its lower face, 1.99 at its upper face.
 static mi_status quantize_nodes4(mi_ctx *c, uint32_t n_total) {
+    mi_status pk = pack_shade(c);
+    if (pk != MI_OK) return pk;
+    HIPCHK(hipStreamSynchronize(c->stream));
     c->sc.qnodes = nullptr;
     for (int a = 0; a < 3; a++) { c->sc.qs[a] = 1.0f; c->sc.qb[a] = 0.0f; }
     const int32_t root = c->sc.root_ref;
