@@ -4,7 +4,8 @@ profiles/roofline_pmc.json (what bench.py reads for its `roofline` object).
 usage: python profiles/tools/pmc_to_json.py <raw dir> <tag> <workload>
 
 Every figure can be recomputed by hand from the committed JSON (raw counters per dispatch are kept):
-  dispatches of one frame, in launch order, per level k: k_tail (k >= 1) | k_extend | k_shade.
+  dispatches of one frame, in launch order, per batch and level k: k_tail (k >= 1) | k_extend | k_shade; counters and
+  durations of a level are summed over the batches of the frame (one stream: `one_frame.py`, `bench.py --streams 1`).
   valu_inst_rate   = 4 * SQ_ACTIVE_INST_VALU / SIMD-cycles      (SQ_ACTIVE_INST_* count quad-cycles; SIMD-cycles =
                      SQ_BUSY_CYCLES / n_SE * n_SIMD: SQ_BUSY_CYCLES is summed over the 32 shader engines)
   lanes_active     = SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU     (of 64)
@@ -45,18 +46,23 @@ def short(name):
     return None
 
 
-def frame_dispatches(rows):
-    """[(kernel, level, counters)] of the render kernels of the frame, in launch order."""
-    out, level = [], {"k_extend": 0, "k_shade": 0, "k_tail": 1}
+def frame_dispatches(rows, levels):
+    """[(kernel, level, counters)] of the render kernels of the frame: per batch and level k the launches are
+    k_tail (k >= 1) | k_extend | k_shade; the counters of the batches of a frame are summed per level."""
+    agg, seen = collections.OrderedDict(), {"k_extend": 0, "k_shade": 0, "k_tail": 0}
     for _, e in sorted(rows.items()):
         k = short(e["kernel"])
-        if k in level:
-            out.append((k, level[k], e["c"]))
-            level[k] += 1
-    return out
+        if k in seen:
+            per = levels if k != "k_tail" else levels - 1
+            lv = seen[k] % per + (1 if k == "k_tail" else 0)
+            seen[k] += 1
+            c = agg.setdefault((k, lv), {})
+            for name, v in e["c"].items():
+                c[name] = c.get(name, 0.0) + v
+    return [(k, lv, c) for (k, lv), c in agg.items()], seen["k_extend"] // max(1, levels)
 
 
-def trace_durations(d, levels):
+def trace_durations(d, levels, batches):
     """Mean duration (ms) per (kernel, level) over the frames of the bench run, and the frame count."""
     fs = glob.glob(f"{d}/*/*kernel_trace.csv") + glob.glob(f"{d}/*kernel_trace.csv")
     seq = collections.defaultdict(list)
@@ -65,22 +71,27 @@ def trace_durations(d, levels):
         if k in ("k_extend", "k_shade", "k_tail") and "k_extend<true" not in r["Kernel_Name"]:
             seq[k].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6)
     dur = {}
-    frames = len(seq["k_extend"]) // levels
+    frames = len(seq["k_extend"]) // (levels * batches)
     for k, v in seq.items():
         per = levels if k != "k_tail" else levels - 1
-        n = len(v) // per
+        n = len(v) // (per * batches)
         for lv in range(per):
-            xs = [v[f * per + lv] for f in range(n)]
-            dur[(k, lv if k != "k_tail" else lv + 1)] = sorted(xs)[len(xs) // 2] if xs else 0.0  # median: the count_work frame's k_shade launches differ
+            # per frame: the sum over its batches; over the frames: the median (the count_work frame's k_shade launches differ)
+            xs = [sum(v[(f * batches + b) * per + lv] for b in range(batches)) for f in range(n)]
+            dur[(k, lv if k != "k_tail" else lv + 1)] = sorted(xs)[len(xs) // 2] if xs else 0.0
     return dur, frames
 
 
 def main():
     raw, tag, workload = sys.argv[1:4]
-    passes = {n: frame_dispatches(counter_rows(os.path.join(raw, n))) for n in ("fetch", "write", "sq", "sq2", "tcc", "tcp", "grbm")}
-    base = passes["sq"]
-    levels = sum(1 for k, _, _ in base if k == "k_extend")
-    dur, frames = trace_durations(os.path.join(raw, "stats"), levels)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    import bench
+    levels = bench.WORKLOADS[workload][3] + 2        # rays per path <= depth + 2: launches per batch and kernel
+    passes, batches = {}, 1
+    for n in ("fetch", "write", "sq", "sq2", "tcc", "tcp", "grbm"):
+        passes[n], nb = frame_dispatches(counter_rows(os.path.join(raw, n)), levels)
+        batches = max(batches, nb)
+    dur, frames = trace_durations(os.path.join(raw, "stats"), levels, batches)
     merged = collections.OrderedDict()
     for n, disp in passes.items():
         for k, lv, c in disp:
@@ -124,7 +135,8 @@ def main():
                                                                      "cycles_per_valu_inst_per_simd") if k in r} for r in rs}}
 
     n_ext = sum(1 for r in recs if r["kernel"] == "k_extend")
-    out = {"tag": tag, "workload": workload, "frames_in_trace": frames, "extend_launches_per_frame": n_ext,
+    n_ext *= batches
+    out = {"tag": tag, "workload": workload, "frames_in_trace": frames, "batches_per_frame": batches, "extend_launches_per_frame": n_ext,
            "definitions": __doc__.split("Every figure")[1].strip(),
            "summary": {k: summary(k) for k in ("k_extend", "k_shade", "k_tail")}, "dispatches": recs}
     with open(os.path.join("profiles", f"{tag}_pmc.json"), "w") as f:
