@@ -264,6 +264,18 @@ def main():
                         "the launches of two streams overlap, see timed_region and frac_timed_region; step_valu_frac is the whole step).  frac_4cycle_slots is the same product priced at one wave64 instruction per 4 cycles per SIMD with the "
                         "clock the PMC pass measured (VALU instruction rate x active lanes / 64).  algorithmic_gbs = SURVEY 8(d) bytes / "
                         "k_extend time: the scene is L1/L2/LDS resident, so that figure is not a roof that binds (hbm_counter_frac is)."}
+        if pmc and world > 1:
+            # a shard of the profiled frame: counter sums scaled by this rank's share of the frame's rays (the PMC pass is of
+            # the whole frame on one GPU; lane operations per ray are a property of code + workload)
+            share = (rays / args.steps) / pmc["rays_cast_frame"] if pmc.get("rays_cast_frame") else None
+            if share:
+                pmc = dict(pmc)
+                for kname in ("k_extend", "k_shade", "k_tail"):
+                    if pmc.get(kname):
+                        pmc[kname] = {k: (v * share if k.endswith("_sum") and k != "duration_ms_sum" else v) for k, v in pmc[kname].items()}
+                pmc["source"] = f"{pmc['source']} scaled by rank 0's share of the frame's rays ({share:.4f})"
+            else:
+                pmc = None
         if pmc:
             ke = pmc["k_extend"]
             # per k_extend launch, like `achieved`: counters of the launches that did work / launches per frame
@@ -346,9 +358,9 @@ def main():
 def pmc_record(workload, world, bvh):
     """Counter-derived figures of the render kernels for this workload from the PMC passes committed under profiles/
     (profiles/roofline_pmc.json, written by profiles/tools/pmc_to_json.py from raw rocprofv3 --pmc output; host-built
-    tree, one GPU).  None if this configuration was not profiled."""
+    tree, the whole frame on one GPU — the caller scales it for a shard).  None if this workload was not profiled."""
     path = os.path.join(ROOT, "profiles", "roofline_pmc.json")
-    if world != 1 or bvh != "host" or not os.path.exists(path):
+    if bvh != "host" or not os.path.exists(path):
         return None
     with open(path) as f:
         rec = json.load(f).get(workload)

@@ -136,6 +136,11 @@ def main():
 
     n_ext = sum(1 for r in recs if r["kernel"] == "k_extend")
     n_ext *= batches
+    rays_frame = None
+    try:  # one_frame.py prints: workload ms_total ms_extend rays_cast
+        rays_frame = int(open(os.path.join(raw, "sq.out")).read().split()[-1])
+    except (OSError, ValueError, IndexError):
+        pass
     out = {"tag": tag, "workload": workload, "frames_in_trace": frames, "batches_per_frame": batches, "extend_launches_per_frame": n_ext,
            "definitions": __doc__.split("Every figure")[1].strip(),
            "summary": {k: summary(k) for k in ("k_extend", "k_shade", "k_tail")}, "dispatches": recs}
@@ -143,7 +148,7 @@ def main():
         json.dump(out, f, indent=1)
     path = os.path.join("profiles", "roofline_pmc.json")
     allw = json.load(open(path)) if os.path.exists(path) else {}
-    allw[workload] = {"tag": tag, "source": f"profiles/{tag}_pmc.json", "extend_launches_per_frame": n_ext, **{k: v for k, v in out["summary"].items()}}
+    allw[workload] = {"tag": tag, "source": f"profiles/{tag}_pmc.json", "extend_launches_per_frame": n_ext, "rays_cast_frame": rays_frame, **{k: v for k, v in out["summary"].items()}}
     with open(path, "w") as f:
         json.dump(allw, f, indent=1)
     s = out["summary"]["k_extend"]
