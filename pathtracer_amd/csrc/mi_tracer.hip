@@ -104,6 +104,8 @@ struct mi_ctx {
     // tuning knobs (defaults measured on MI355X, overridable through the environment)
     int extend_wg_per_cu = 7;   // MI_TRACER_EXTEND_WG_PER_CU: persistent workgroups of k_extend per CU (clamped by the occupancy query)
     int extend_wg_primary = 6;  // the same for the level-0 variant, which holds more registers
+    int extend_wg_two = 6;      // MI_TRACER_EXTEND_WG_TWO_STREAMS: workgroups of the secondary k_extend per CU when the batches run on two
+                                // streams — one resident slot left to the other stream's kernels: C3 +3 %, C4 +2 % against 7; 5 loses
     int refill_min = 20;        // MI_TRACER_REFILL: idle lanes that trigger a refill
     int refill_primary = 12;    // MI_TRACER_REFILL_PRIMARY: the same at level 0, where a refill only reads parked camera rays
     int leaf_min = 16;          // MI_TRACER_LEAF_MIN: lanes with a pending leaf that trigger a leaf phase
@@ -177,6 +179,7 @@ MI_API mi_status mi_ctx_create(int device_id, mi_ctx **out) {
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_e, k_extend<false, true, false>, MI_BLOCK, 0) == hipSuccess && occ_e > 0)
         c->extend_wg_primary = std::min(c->extend_wg_primary, occ_e);
     c->extend_wg_primary = env_int("MI_TRACER_EXTEND_WG_PRIMARY", 1, 16, c->extend_wg_primary); // stack_grid() covers whatever is chosen
+    c->extend_wg_two = std::min(c->extend_wg_per_cu, env_int("MI_TRACER_EXTEND_WG_TWO_STREAMS", 1, 16, c->extend_wg_two));
     // k_tail is persistent and deals its work statically over the grid: launch exactly as many
     // workgroups as are resident at once (a second round would start after the first has finished).
     // Computed after extend_wg_per_cu is final; the overflow stacks are sized for the largest of the
@@ -1124,7 +1127,8 @@ MI_API mi_status mi_render_device(mi_ctx *c, const mi_render_params *p, void *d_
         for (int i = 0; i < 2; i++) { m.ray_o[i] = pb.ray_o[i].as<float4>(); m.ray_d[i] = pb.ray_d[i].as<float4>(); m.thr[i] = pb.thr[i].as<float4>(); }
         m.hits = pb.hits.as<float2>(); m.path_out = pb.path_out.as<float4>(); m.hist = pb.hist.as<float4>();
         m.counters = pb.counters.as<uint32_t>(); m.ovf = pb.ovf.as<int>(); m.totals = pb.totals.as<uint64_t>();
-        m.egrid = extend_grid(c); m.egrid0 = c->n_cu * c->extend_wg_primary; m.tgrid = c->n_cu * c->tail_wg_per_cu;
+        m.egrid = n_sets > 1 ? c->n_cu * c->extend_wg_two : extend_grid(c);
+        m.egrid0 = c->n_cu * c->extend_wg_primary; m.tgrid = c->n_cu * c->tail_wg_per_cu;
     }
     return render_batches(c, p, g, bp, sets, n_sets, d_rgba_mean, d_rgba8, st, stats, true, true);
 }
