@@ -666,6 +666,10 @@ k_extend(DevScene sc, const uint32_t *count_ptr, uint32_t fixed_count, uint32_t 
     const uint32_t n_waves = gridDim.x * (MI_BLOCK / 64);
     const uint32_t wave_id = __builtin_amdgcn_readfirstlane(blockIdx.x * (MI_BLOCK / 64) + (threadIdx.x >> 6));
     const uint32_t n_chunks = stream_chunks(count_ptr, fixed_count);
+#ifdef MI_WAVE_TIMES
+    const unsigned long long wt_start = wall_clock64();
+    uint32_t wt_iters = 0;
+#endif
     ChunkDeal deal = deal_start(wave_id, n_waves, deal_rot);
     uint32_t chunk = deal_chunk(deal);  // next virtual chunk of this wave (wave-uniform)
     uint32_t rng_next = 0, rng_end = 0; // wave-uniform, ray positions
@@ -750,6 +754,9 @@ k_extend(DevScene sc, const uint32_t *count_ptr, uint32_t fixed_count, uint32_t 
             more = rng_next < rng_end || chunk < n_chunks;
         }
         if (COUNT) wave_iters++;
+#ifdef MI_WAVE_TIMES
+        wt_iters++;
+#endif
         const bool want_leaf = active && L.cur < 0;
         const bool want_node = active && L.cur >= 0 && L.cur != MI_DONE;
         const int nl = __popcll(__ballot(want_leaf)), nn = __popcll(__ballot(want_node));
@@ -786,6 +793,17 @@ k_extend(DevScene sc, const uint32_t *count_ptr, uint32_t fixed_count, uint32_t 
         act = __ballot(active);
     } while (more || act != 0ull);
     if (PRIMARY && lane == 0 && n_primary) atomicAdd(primary_count, n_primary);
+#ifdef MI_WAVE_TIMES
+    // Diagnostic build (-DMI_WAVE_TIMES, MI_TRACER_WAVE_TIMES=<file>; scratch/wt.sh, scratch/wt.py): when each wave
+    // started and left (100 MHz clock), where it ran (HW_ID, XCC_ID), how many iterations it made.
+    if (!COUNT && work_stats && lane == 0 && level < 8 && wave_id < 8192) {
+        unsigned long long *w = work_stats + ((size_t)level * 8192 + wave_id) * 4;
+        w[0] = wt_start;
+        w[1] = wall_clock64();
+        w[2] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | (uint32_t)__builtin_amdgcn_s_getreg(63492);
+        w[3] = wt_iters;
+    }
+#endif
     if (COUNT) {
         atomicMax(&work_stats[2], (unsigned long long)max_ray_steps);
         if (lane == 0) { atomicAdd(&work_stats[3], (unsigned long long)wave_iters); atomicMax(&work_stats[4], (unsigned long long)wave_iters); }

@@ -941,6 +941,9 @@ struct PathMem {
 // n_sets = 2: the batches alternate between the caller's stream (set 0) and the context's second stream (set 1),
 // each with its own path state, so that the sparse end of one batch — the last waves of every launch and the
 // latency-bound k_tail — runs beside the dense start of the next.  Every batch writes its own pixels.
+#ifdef MI_WAVE_TIMES
+static unsigned long long *g_wt_buf = nullptr; // diagnostic build only: per-wave time stamps of the k_extend launches (mi_kernels.h)
+#endif
 static mi_status render_batches(mi_ctx *c, const mi_render_params *p, const ShardGeom &g, const BatchPlan &bp, const PathMem *sets, int n_sets,
                                 void *d_rgba_mean, void *d_rgba8, hipStream_t st, mi_stats *stats, bool timed, bool sync) {
     const int64_t local = shard_pixels(g);
@@ -984,6 +987,10 @@ static mi_status render_batches(mi_ctx *c, const mi_render_params *p, const Shar
         for (int k = 0; k < levels; k++) {
             const RayStream &sin = rs[k & 1], &sout = rs[(k + 1) & 1];
             unsigned long long *ws = count_work ? (unsigned long long *)m.totals + 2 : nullptr;
+#ifdef MI_WAVE_TIMES
+            if (!g_wt_buf && getenv("MI_TRACER_WAVE_TIMES")) HIPCHK(hipMalloc((void **)&g_wt_buf, 8 * 8192 * 32));
+            if (!count_work && g_wt_buf) { ws = g_wt_buf; if (k == 0) HIPCHK(hipMemsetAsync(g_wt_buf, 0, 8 * 8192 * 32, bs)); }
+#endif
             if (per_launch) HIPCHK(hipEventRecord(c->ev[evi++], bs)); // 4 events per level: tail | extend | shade
             if (k >= 1 && c->tail_threshold > 0 && !count_work)
                 hipLaunchKernelGGL(k_tail, dim3(m.tgrid), dim3(MI_BLOCK), 0, bs, c->sc, g, pix0, np, d_np, k, p->depth, p->seed, sin, cnt + k * kLevelWords,
@@ -1026,6 +1033,15 @@ static mi_status render_batches(mi_ctx *c, const mi_render_params *p, const Shar
     HIPCHK(hipStreamSynchronize(st));
     for (int s = 1; s < n_sets; s++) // the two sets' totals are sums, except two maxima (slots 4 and 6)
         for (int k = 0; k < kTotals; k++) c->h_totals[k] = (k == 4 || k == 6) ? std::max(c->h_totals[k], c->h_totals[s * kTotals + k]) : c->h_totals[k] + c->h_totals[s * kTotals + k];
+#ifdef MI_WAVE_TIMES
+    if (const char *wt_path = getenv("MI_TRACER_WAVE_TIMES")) { // the last batch's launches
+        std::vector<unsigned long long> h(8 * 8192 * 4);
+        if (g_wt_buf) {
+            HIPCHK(hipMemcpy(h.data(), g_wt_buf, h.size() * 8, hipMemcpyDeviceToHost));
+            if (FILE *f = fopen(wt_path, "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
+        }
+    }
+#endif
     if (stats) {
         memset(stats, 0, sizeof *stats);
         stats->rays_cast = c->h_totals[0];
