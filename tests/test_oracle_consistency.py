@@ -88,3 +88,25 @@ def test_noise_floor_between_seeds_is_what_raycheck_would_see(scenes_small):
         b = O.render(sc, P.Context.params(w, h, s, 2, seed=2))[1]
         rms.append(O.raycheck_rms(a, b))
     assert rms[1] < rms[0] and rms[0] > 5
+
+
+def test_noise_floor_aware_verdict_catches_what_the_fixed_threshold_misses(scenes_small):
+    # raycheck.check: a correct render with another seed is inside the noise band of the settings; an image that is
+    # 4 % too dark passes the reference's fixed RMS < 10 but not the band; a noisy low-sample pair exceeds 10 and is
+    # still correct.
+    from pathtracer_amd import raycheck
+    sc = scenes_small["simple"]
+    w, h = sc.image_size(32)
+    r = lambda s, seed: O.render(sc, P.Context.params(w, h, s, 2, seed=seed))[1]
+    a, b, c, ref = r(16, 1), r(16, 2), r(16, 3), r(16, 4)
+    floor = raycheck.noise_floor([a, b, c])
+    assert 0 < floor < 5
+    good = raycheck.rms(a, ref)
+    assert raycheck.check(good, floor=floor) and raycheck.check(good)
+    dark = np.floor(a.astype(np.float64) * 0.96).astype(np.uint8)
+    bad = raycheck.rms(dark, ref)
+    assert raycheck.check(bad) and not raycheck.check(bad, floor=floor), (bad, floor)
+    n1, n2, n3 = r(2, 1), r(2, 2), r(2, 3)
+    noisy_floor = raycheck.noise_floor([n1, n2])
+    noisy = raycheck.rms(n3, n1)
+    assert noisy > 10 and not raycheck.check(noisy) and raycheck.check(noisy, floor=noisy_floor), (noisy, noisy_floor)
