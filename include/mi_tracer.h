@@ -122,12 +122,16 @@ typedef struct mi_render_params {
  * the image does not depend on it.  This bit keeps every batch on the one stream of the call: each kernel then
  * has the chip to itself, which is what a per-kernel measurement wants. */
 #define MI_RENDER_ONE_STREAM 1
+/* Per-kernel times (mi_stats.ms_extend / ms_shade / ms_tail / extend_launches) need an event around every launch:
+ * 4 per level and batch, ~0.15 ms of a 6.5 ms frame.  They are recorded only on request (or with
+ * MI_TRACER_DEBUG_LEVELS in the environment); without this bit those fields are 0 and ms_other = ms_total. */
+#define MI_RENDER_LAUNCH_TIMES 2
 
 typedef struct mi_stats {
     uint64_t rays_cast;      /* closest-hit queries issued (primary + bounce)       */
     uint64_t paths;          /* paths started                                       */
     double ms_total;         /* first launch -> outputs complete (HIP events)       */
-    double ms_extend;        /* sum over launches of the BVH extend kernel          */
+    double ms_extend;        /* sum over launches of the BVH extend kernel (MI_RENDER_LAUNCH_TIMES) */
     double ms_shade;         /* sum over launches of the shade+compact kernel       */
     double ms_other;         /* everything else (resolve, memsets, gaps)             */
     uint32_t extend_launches;

@@ -134,7 +134,7 @@ static int extend_grid(const mi_ctx *c) { return c->n_cu * c->extend_wg_per_cu; 
 static int stack_grid(const mi_ctx *c) { return c->n_cu * std::max(c->extend_wg_per_cu, std::max(c->extend_wg_primary, c->tail_wg_per_cu)); }
 static size_t stack_bytes(const mi_ctx *c) { return (size_t)(MI_MAX_STACK - MI_LDS_STACK) * stack_grid(c) * MI_BLOCK * 4; }
 
-MI_API int mi_abi_version(void) { return 11; }
+MI_API int mi_abi_version(void) { return 12; }
 MI_API const char *mi_last_error(void) { return g_err.c_str(); }
 
 MI_API mi_status mi_ctx_create(int device_id, mi_ctx **out) {
@@ -958,7 +958,7 @@ static mi_status render_batches(mi_ctx *c, const mi_render_params *p, const Shar
     const int64_t n_batches = local > 0 ? (local + npix_b - 1) / npix_b : 0;
     if (n_batches < 2) n_sets = 1;
     const size_t n_ev = 2 + (size_t)n_batches * levels * 4;
-    const bool per_launch = timed && n_ev <= 4096; // per-launch timing only while the event count stays modest
+    const bool per_launch = timed && n_ev <= 4096 && ((p->flags & MI_RENDER_LAUNCH_TIMES) || getenv("MI_TRACER_DEBUG_LEVELS")); // on request, and only while the event count stays modest
     if (timed) {
         mi_status es = get_events(c, per_launch ? n_ev : 2);
         if (es != MI_OK) return es;
@@ -970,57 +970,80 @@ static mi_status render_batches(mi_ctx *c, const mi_render_params *p, const Shar
         HIPCHK(hipEventRecord(c->ev_fork, st));
         HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
     }
-    size_t evi = 2;
-    for (int64_t b = 0; b < n_batches; b++) {
+    // One batch = begin (counters cleared), `levels` x (k_tail | k_extend | k_shade), end (resolve, totals); every
+    // batch on the stream of its set.  (Enqueuing the launches of two neighbouring batches level by level instead of
+    // batch by batch — so that the second stream starts at once instead of ~0.8 ms of launch calls later — measured
+    // the same step time at every stagger.)
+    struct Batch { uint32_t pix0, np, rot0; int64_t nslots; FastDiv d_np; };
+    auto batch_of = [&](int64_t b, Batch &B) -> bool {
+        B.pix0 = (uint32_t)(b * npix_b);
+        B.np = (uint32_t)std::min<int64_t>(npix_b, local - (int64_t)B.pix0);
+        B.nslots = (int64_t)B.np * spp;
+        B.rot0 = deal_rotation((uint32_t)sets[b % n_sets].egrid0 * (MI_BLOCK / 64), B.np, spp);
+        return fastdiv_make(B.np, B.d_np);
+    };
+    auto begin = [&](int64_t b) -> hipError_t { return hipMemsetAsync(sets[b % n_sets].counters, 0, kCounterWords * 4, streams[b % n_sets]); };
+    auto level = [&](int64_t b, const Batch &B, int k) -> hipError_t {
         const PathMem &m = sets[b % n_sets];
         hipStream_t bs = streams[b % n_sets];
         uint32_t *cnt = m.counters;                                   // cnt[k*kLevelWords + j*MI_CNT_STRIDE] = rays in sub-stream j of level k
         uint32_t *tail_level = cnt + (kMaxLevels + 1) * kLevelWords;  // 0, or the level at which k_tail took over
         const RayStream rs[2] = {{m.ray_o[0], m.ray_d[0], m.thr[0], segcap}, {m.ray_o[1], m.ray_d[1], m.thr[1], segcap}};
-        const uint32_t pix0 = (uint32_t)(b * npix_b);
-        const uint32_t np = (uint32_t)std::min<int64_t>(npix_b, local - (int64_t)pix0);
-        const int64_t nslots = (int64_t)np * spp;
-        const uint32_t rot0 = deal_rotation((uint32_t)m.egrid0 * (MI_BLOCK / 64), np, spp);
-        FastDiv d_np;
-        if (!fastdiv_make(np, d_np)) return fail(MI_ERR_INVALID, "internal: division constants failed their check");
-        HIPCHK(hipMemsetAsync(cnt, 0, kCounterWords * 4, bs));
-        for (int k = 0; k < levels; k++) {
-            const RayStream &sin = rs[k & 1], &sout = rs[(k + 1) & 1];
-            unsigned long long *ws = count_work ? (unsigned long long *)m.totals + 2 : nullptr;
+        const uint32_t pix0 = B.pix0, np = B.np, rot0 = B.rot0;
+        const int64_t nslots = B.nslots;
+        const FastDiv d_np = B.d_np;
+        size_t evi = 2 + ((size_t)b * levels + k) * 4;
+        hipError_t e = hipSuccess;
+#define MI_EV() if (per_launch && (e = hipEventRecord(c->ev[evi++], bs)) != hipSuccess) return e
+        const RayStream &sin = rs[k & 1], &sout = rs[(k + 1) & 1];
+        unsigned long long *ws = count_work ? (unsigned long long *)m.totals + 2 : nullptr;
 #ifdef MI_WAVE_TIMES
-            if (!g_wt_buf && getenv("MI_TRACER_WAVE_TIMES")) HIPCHK(hipMalloc((void **)&g_wt_buf, 8 * 8192 * 32));
-            if (!count_work && g_wt_buf) { ws = g_wt_buf; if (k == 0) HIPCHK(hipMemsetAsync(g_wt_buf, 0, 8 * 8192 * 32, bs)); }
+        if (!g_wt_buf && getenv("MI_TRACER_WAVE_TIMES") && (e = hipMalloc((void **)&g_wt_buf, 8 * 8192 * 32)) != hipSuccess) return e;
+        if (!count_work && g_wt_buf) { ws = g_wt_buf; if (k == 0 && (e = hipMemsetAsync(g_wt_buf, 0, 8 * 8192 * 32, bs)) != hipSuccess) return e; }
 #endif
-            if (per_launch) HIPCHK(hipEventRecord(c->ev[evi++], bs)); // 4 events per level: tail | extend | shade
-            if (k >= 1 && c->tail_threshold > 0 && !count_work)
-                hipLaunchKernelGGL(k_tail, dim3(m.tgrid), dim3(MI_BLOCK), 0, bs, c->sc, g, pix0, np, d_np, k, p->depth, p->seed, sin, cnt + k * kLevelWords,
-                                   (uint32_t)c->tail_threshold, tail_level, m.hist, cap, (size_t)hist_levels * cap, m.path_out, m.ovf,
-                                   (unsigned long long *)m.totals + 7, c->shade_min, c->tail_refill);
-            if (per_launch) HIPCHK(hipEventRecord(c->ev[evi++], bs));
+        MI_EV(); // 4 events per level: tail | extend | shade
+        if (k >= 1 && c->tail_threshold > 0 && !count_work)
+            hipLaunchKernelGGL(k_tail, dim3(m.tgrid), dim3(MI_BLOCK), 0, bs, c->sc, g, pix0, np, d_np, k, p->depth, p->seed, sin, cnt + k * kLevelWords,
+                               (uint32_t)c->tail_threshold, tail_level, m.hist, cap, (size_t)hist_levels * cap, m.path_out, m.ovf,
+                               (unsigned long long *)m.totals + 7, c->shade_min, c->tail_refill);
+        MI_EV();
 #define MI_EXTEND_ARGS(PRIM)                                                                                                   \
     dim3((PRIM) ? m.egrid0 : m.egrid), dim3(MI_BLOCK), 0, bs, c->sc, (PRIM) ? (const uint32_t *)nullptr : cnt + k * kLevelWords,                   \
         (PRIM) ? (uint32_t)nslots : 0u, segcap, sin.o, sin.d, m.hits, m.ovf, ws,                          \
         (PRIM) ? c->refill_primary : c->refill_min, c->leaf_min, g, pix0, np, d_np, cnt, tail_level, k, (PRIM) ? rot0 : 0u
-            if (k == 0) {
-                if (count_work) hipLaunchKernelGGL((k_extend<true, true>), MI_EXTEND_ARGS(true));
-                else hipLaunchKernelGGL((k_extend<false, true>), MI_EXTEND_ARGS(true));
-            } else {
-                if (count_work) hipLaunchKernelGGL((k_extend<true, false>), MI_EXTEND_ARGS(false));
-                else hipLaunchKernelGGL((k_extend<false, false>), MI_EXTEND_ARGS(false));
-            }
+        if (k == 0) {
+            if (count_work) hipLaunchKernelGGL((k_extend<true, true>), MI_EXTEND_ARGS(true));
+            else hipLaunchKernelGGL((k_extend<false, true>), MI_EXTEND_ARGS(true));
+        } else {
+            if (count_work) hipLaunchKernelGGL((k_extend<true, false>), MI_EXTEND_ARGS(false));
+            else hipLaunchKernelGGL((k_extend<false, false>), MI_EXTEND_ARGS(false));
+        }
 #undef MI_EXTEND_ARGS
-            if (per_launch) HIPCHK(hipEventRecord(c->ev[evi++], bs));
+        MI_EV();
 #define MI_SHADE_ARGS                                                                                                          \
     dim3(sgrid), dim3(MI_BLOCK), 0, bs, c->sc, g, pix0, np, d_np, k, p->depth - k, p->seed, sin, cnt + k * kLevelWords, m.hits,         \
         m.hist, cap, (size_t)hist_levels * cap, m.path_out, sout, cnt + (k + 1) * kLevelWords, (uint32_t)nslots, tail_level
-            if (k == 0) hipLaunchKernelGGL(k_shade<true>, MI_SHADE_ARGS);
-            else hipLaunchKernelGGL(k_shade<false>, MI_SHADE_ARGS);
+        if (k == 0) hipLaunchKernelGGL(k_shade<true>, MI_SHADE_ARGS);
+        else hipLaunchKernelGGL(k_shade<false>, MI_SHADE_ARGS);
 #undef MI_SHADE_ARGS
-            if (per_launch) HIPCHK(hipEventRecord(c->ev[evi++], bs));
-        }
-        hipLaunchKernelGGL(k_resolve, dim3((np + MI_BLOCK - 1) / MI_BLOCK), dim3(MI_BLOCK), 0, bs, g, pix0, np, m.path_out,
+        MI_EV();
+#undef MI_EV
+        return hipSuccess;
+    };
+    auto end = [&](int64_t b, const Batch &B) {
+        const PathMem &m = sets[b % n_sets];
+        hipStream_t bs = streams[b % n_sets];
+        hipLaunchKernelGGL(k_resolve, dim3((B.np + MI_BLOCK - 1) / MI_BLOCK), dim3(MI_BLOCK), 0, bs, g, B.pix0, B.np, m.path_out,
                            (float4 *)d_rgba_mean, (uchar4 *)d_rgba8);
-        hipLaunchKernelGGL(k_sum_counts, dim3(1), dim3(64), 0, bs, cnt, levels, m.totals, tail_level);
+        hipLaunchKernelGGL(k_sum_counts, dim3(1), dim3(64), 0, bs, m.counters, levels, m.totals, m.counters + (kMaxLevels + 1) * kLevelWords);
+    };
+    const size_t evi = 2 + (size_t)n_batches * levels * 4;
+    for (int64_t b = 0; b < n_batches; b++) {
+        Batch B;
+        if (!batch_of(b, B)) return fail(MI_ERR_INVALID, "internal: division constants failed their check");
+        HIPCHK(begin(b));
+        for (int k = 0; k < levels; k++) HIPCHK(level(b, B, k));
+        end(b, B);
     }
     HIPCHK(hipGetLastError());
     if (n_sets > 1) { // join: the caller's stream continues when the second stream has finished its batches
@@ -1090,6 +1113,8 @@ static mi_status render_batches(mi_ctx *c, const mi_render_params *p, const Shar
             stats->ms_extend = me;
             stats->ms_shade = msh;
             stats->ms_other = std::max(0.0, stats->ms_total - me - msh - mt);
+        } else {
+            stats->ms_other = stats->ms_total; // no per-kernel times without MI_RENDER_LAUNCH_TIMES
         }
     }
     return MI_OK;

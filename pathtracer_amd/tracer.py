@@ -89,9 +89,9 @@ class Context:
         return ids
 
     @staticmethod
-    def params(width, height, samples, depth, seed=0, tile=(0, 0), shard=(0, 1), batch_paths=0, count_work=False, one_stream=False):
+    def params(width, height, samples, depth, seed=0, tile=(0, 0), shard=(0, 1), batch_paths=0, count_work=False, one_stream=False, launch_times=False):
         return N.RenderParams(width, height, samples, depth, seed, tile[0], tile[1], shard[0], shard[1], batch_paths,
-                              1 if count_work else 0, N.MI_RENDER_ONE_STREAM if one_stream else 0)
+                              1 if count_work else 0, (N.MI_RENDER_ONE_STREAM if one_stream else 0) | (N.MI_RENDER_LAUNCH_TIMES if launch_times else 0))
 
     def render(self, params, want_mean=True, want_rgb8=True):
         """Host-buffer render.  Returns (mean float32[h,w,4] | None, rgb8 uint8[h,w,3] | None, Stats);
