@@ -372,7 +372,7 @@ k_build_permute(int n, uint32_t n_tri, uint32_t *sorted_slot, const uint32_t *tr
     uint32_t now;
     if (old < n_tri) {
         now = tri_rank[i];
-        for (int k = 0; k < 4; k++) dst.tri[4 * (size_t)now + k] = src.tri[4 * (size_t)old + k];
+        for (int k = 0; k < 3; k++) dst.tri[3 * (size_t)now + k] = src.tri[3 * (size_t)old + k]; // 48-B records (mi_kernels.h)
         dst.tri_normal[now] = src.tri_normal[old];
         for (int k = 0; k < 3; k++) dst.tri_mat[3 * (size_t)now + k] = src.tri_mat[3 * (size_t)old + k];
         dst.tri_has_vmat[now] = src.tri_has_vmat[old];

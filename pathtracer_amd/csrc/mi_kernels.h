@@ -37,7 +37,7 @@ struct DevScene {
     // (q_encode in mi_bvh_build.h), so a quantised box encloses the fp32 box it was made from.
     const uint4 *qnodes;
     float qs[3], qb[3];
-    const float4 *tri;   // 4 x float4 per triangle slot: v0, uInv, vInv, nInv
+    const float4 *tri;   // 48 B per triangle slot: v0.xyz, uInv.xyz, vInv.xyz, nInv.xyz (the w lanes are +0 and unused), + 16 B behind the last
     const float4 *tri_normal;
     const uint32_t *tri_mat; // 3 per triangle
     const uint8_t *tri_has_vmat;
@@ -350,26 +350,30 @@ __device__ __forceinline__ bool tie_allows(const DevScene &sc, int best_slot, in
     return best_is_sphere ? (cid < bid) : false;
 }
 
-// trimesh.cu:87-121.  Evaluated without early exits: all four 16-B loads of the 64-B
+// trimesh.cu:87-121.  Evaluated without early exits: the three 16-B loads of the 48-B
 // record are issued together (one memory round trip instead of two) and the reject
 // tests of :92, :96 and :104 — each a pure function of the same values — are combined
 // at the end.  The accepted (t, u, v) are the reference's.
-__device__ __forceinline__ void tri_test_rec(const DevScene &sc, int slot, float4 v0, float4 ui, float4 vi, float4 ni, f3 o, f3 d, Hit &h) {
-    f3 p = o - xyz(v0);
-    float pz = dot3w(xyz(ni), p);
-    float dz = dot3w(xyz(ni), d);
+// The record is three float4: (v0.xyz, uInv.x) (uInv.yz, vInv.xy) (vInv.z, nInv.xyz) — 48 B, three loads; the fourth
+// lanes of the reference's vectors are +0 in every loadable scene and enter no result.
+#define MI_TRI_BYTES 48u
+__device__ __forceinline__ void tri_test_rec(const DevScene &sc, int slot, float4 ra, float4 rb, float4 rc, f3 o, f3 d, Hit &h) {
+    const f3 v0 = mk3(ra.x, ra.y, ra.z), ui = mk3(ra.w, rb.x, rb.y), vi = mk3(rb.z, rb.w, rc.x), ni = mk3(rc.y, rc.z, rc.w);
+    f3 p = o - v0;
+    float pz = dot3w(ni, p);
+    float dz = dot3w(ni, d);
     float t = -pz / dz;
     f3 hit = p + t * d;
-    float u = dot3(xyz(ui), hit);
-    float v = dot3(xyz(vi), hit);
+    float u = dot3(ui, hit);
+    float v = dot3(vi, hit);
     bool ok = ((pz < 0) != (dz < 0)) && !(t > h.t) && !(u < 0 || u > 1 || v < 0 || v > 1 || u + v > 1);
     if (ok && t == h.t) ok = tie_allows(sc, h.slot, slot, true);
     if (ok) { h.t = t; h.slot = slot; }
 }
 __device__ __forceinline__ void tri_test(const DevScene &sc, int slot, f3 o, f3 d, Hit &h) {
-    const char *rec = (const char *)sc.tri + ((uint32_t)slot << 6);
-    float4 v0 = *(const float4 *)(rec), ui = *(const float4 *)(rec + 16), vi = *(const float4 *)(rec + 32), ni = *(const float4 *)(rec + 48);
-    tri_test_rec(sc, slot, v0, ui, vi, ni, o, d, h);
+    const char *rec = (const char *)sc.tri + (size_t)(uint32_t)slot * MI_TRI_BYTES;
+    const float4 ra = *(const float4 *)(rec), rb = *(const float4 *)(rec + 16), rc = *(const float4 *)(rec + 32);
+    tri_test_rec(sc, slot, ra, rb, rc, o, d, h);
 }
 
 __device__ __forceinline__ void sphere_test_rec(const DevScene &sc, int slot, float4 cr, f3 o, f3 d, Hit &h) { // sphere.cu:5-35
@@ -582,8 +586,8 @@ __device__ __forceinline__ void node_phase(const DevScene &sc, Lane &L, lds_int 
     node_process<true>(sc, L, stack, my_ovf, ovf_stride, px, py, pz, refs);
 }
 // Leaf lanes and node lanes in ONE step (draining waves and k_tail, whose time is a chain of latencies): every lane
-// with work fetches the 64 B its ref names — a quantised node, a triangle record, or a sphere (16 B used; the
-// sphere array is padded so that the 64-B read stays inside it) — with the same four loads, the wave waits once,
+// with work fetches what its ref names — a quantised node (64 B), a triangle record (48 B), or a sphere (16 B used; the
+// sphere array is padded so that the 48-B read stays inside it) — with the same loads (a node four of 16 B, a primitive three), the wave waits once,
 // both kinds compute, and one stack read serves every lane that needs its next ref.  (Two separate phases per
 // iteration paid two memory round trips and two stack round trips.)  ANY: the first accepted primitive ends the query.
 template <bool ANY>
@@ -593,12 +597,14 @@ __device__ __forceinline__ void merged_step(const DevScene &sc, Lane &L, lds_int
     const int slot = ~L.cur;
     const bool is_sph = want_leaf && (uint32_t)slot >= sc.n_tri;
     const char *at = want_node ? node_addr(sc, L.cur, nb)
-                               : (is_sph ? (const char *)sc.sph + ((uint32_t)(slot - (int)sc.n_tri) << 4) : (const char *)sc.tri + ((uint32_t)slot << 6));
-    const uint4 r0 = *(const uint4 *)(at), r1 = *(const uint4 *)(at + 16), r2 = *(const uint4 *)(at + 32), r3 = *(const uint4 *)(at + 48);
+                               : (is_sph ? (const char *)sc.sph + ((uint32_t)(slot - (int)sc.n_tri) << 4) : (const char *)sc.tri + (size_t)(uint32_t)slot * MI_TRI_BYTES);
+    const uint4 r0 = *(const uint4 *)(at), r1 = *(const uint4 *)(at + 16), r2 = *(const uint4 *)(at + 32);
+    uint4 r3 = make_uint4(0u, 0u, 0u, 0u);
+    if (want_node) r3 = *(const uint4 *)(at + 48); // the refs: only a node has a fourth quarter
     auto f4 = [](uint4 r) { return make_float4(__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w)); };
     if (want_leaf) {
         if (is_sph) sphere_test_rec(sc, slot, f4(r0), L.o, L.d, L.h);
-        else tri_test_rec(sc, slot, f4(r0), f4(r1), f4(r2), f4(r3), L.o, L.d, L.h);
+        else tri_test_rec(sc, slot, f4(r0), f4(r1), f4(r2), L.o, L.d, L.h);
         L.cur = MI_NONE;
         if (ANY && L.h.slot >= 0) { L.cur = MI_DONE; L.sp = 0; }
     } else {
@@ -856,10 +862,11 @@ __device__ __forceinline__ void hit_surface(const DevScene &sc, const MatTable &
         const uint32_t mid[3] = {s1.x, s1.y, s1.z};
         if (s0.w) { // trimesh.cu:110-116 with material.h:91-100,137-146
             // u, v of trimesh.cu:98-101 again, from the accepted t: the operations of tri_test on the same inputs
-            const char *rec = (const char *)sc.tri + ((uint32_t)slot << 6);
-            const float4 v0 = *(const float4 *)(rec), ui = *(const float4 *)(rec + 16), vi = *(const float4 *)(rec + 32);
-            const f3 hit = (o - xyz(v0)) + t * d;
-            const float u = dot3(xyz(ui), hit), v = dot3(xyz(vi), hit);
+            const char *rec = (const char *)sc.tri + (size_t)(uint32_t)slot * MI_TRI_BYTES;
+            const float4 ra = *(const float4 *)(rec), rb = *(const float4 *)(rec + 16);
+            const float vz = *(const float *)(rec + 32);
+            const f3 hit = (o - mk3(ra.x, ra.y, ra.z)) + t * d;
+            const float u = dot3(mk3(ra.w, rb.x, rb.y), hit), v = dot3(mk3(rb.z, rb.w, vz), hit);
             float w = 1 - u - v;     // trimesh.cu:102
             // (a*w + b*u) + c*v, accumulated one vertex material at a time (same
             // association, a third of the registers of loading all three first)

@@ -378,15 +378,16 @@ static mi_status upload_prims(mi_ctx *c, const mi_scene_soa *s) {
         if (e != hipSuccess || bytes == 0) return e;
         return hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice);
     };
-    // interleave v0,uInv,vInv,nInv into one 64-B record per triangle
-    std::vector<float> rec(16 * nt);
+    // v0, uInv, vInv, nInv (xyz of each: the fourth lanes are unused) into one 48-B record per triangle, + 16 B
+    // behind the last: merged_step's node-shaped fetch never reads them, a record's three loads stay inside
+    std::vector<float> rec(12 * nt + 4, 0.0f);
     for (size_t i = 0; i < nt; i++) {
-        memcpy(&rec[16 * i + 0], s->tri_v0 + 4 * i, 16);
-        memcpy(&rec[16 * i + 4], s->tri_uinv + 4 * i, 16);
-        memcpy(&rec[16 * i + 8], s->tri_vinv + 4 * i, 16);
-        memcpy(&rec[16 * i + 12], s->tri_ninv + 4 * i, 16);
+        memcpy(&rec[12 * i + 0], s->tri_v0 + 4 * i, 12);
+        memcpy(&rec[12 * i + 3], s->tri_uinv + 4 * i, 12);
+        memcpy(&rec[12 * i + 6], s->tri_vinv + 4 * i, 12);
+        memcpy(&rec[12 * i + 9], s->tri_ninv + 4 * i, 12);
     }
-    HIPCHK(up(c->tri, rec.data(), nt * 64));
+    HIPCHK(up(c->tri, rec.data(), nt * 48 + 16));
     HIPCHK(up(c->tri_normal, s->tri_normal, nt * 16));
     HIPCHK(up(c->tri_mat, s->tri_mat, nt * 12));
     HIPCHK(up(c->tri_has_vmat, s->tri_has_vmat, nt));
@@ -673,7 +674,7 @@ MI_API mi_status mi_scene_upload_build(mi_ctx *c, const mi_scene_soa *s, const f
         // primitives into Morton order (per class), prim_id and boxes along with them
         {
             const size_t nt = s->n_tri, ns = s->n_sph;
-            HIPCHK(r_tri.ensure(std::max<size_t>(nt * 64, 16)));
+            HIPCHK(r_tri.ensure(nt * 48 + 16));
             HIPCHK(r_nrm.ensure(std::max<size_t>(nt * 16, 16)));
             HIPCHK(r_mat.ensure(std::max<size_t>(nt * 12, 16)));
             HIPCHK(r_vm.ensure(std::max<size_t>(nt, 16)));
