@@ -73,3 +73,19 @@ def test_glass_depth8_bands_match_oracle(ctx):
     for y0 in (100, 300):
         om, orgb, _ = O.render(sc, p, rows=(y0, y0 + 3))
         assert np.array_equal(rgb[y0:y0 + 3], orgb[y0:y0 + 3])
+
+
+def test_c1_and_c2_whole_frames_match_oracle_bitwise(ctx):
+    # BASELINE configs 0 and 1 at their full sizes, every pixel: C1 simple scene 256x257, 1 spp, depth 2 (CpuTracer's own
+    # runnable case); C2 Cornell box 512x513, 64 spp, depth 5 (16.8 M paths, ~110 M rays: seconds of oracle time).
+    for text, width, s, depth in ((scenes.simple_ray(), 256, 1, 2), (scenes.cornell_ray(), 512, 8, 5)):
+        sc = P.Scene.from_text(text)
+        w, h = sc.image_size(width)
+        ctx.upload(sc)
+        p = P.Context.params(w, h, s, depth, seed=0)
+        mean, rgb, st = ctx.render(p)
+        om, orgb, cnt = O.render(sc, p, threads=16)
+        assert (w, h) == (width, width + 1)                     # CommandLineUI.cu:83-84 with aspect 1
+        assert st.rays_cast == cnt.rays and st.paths == w * h * s * s
+        assert np.array_equal(rgb, orgb)
+        assert np.array_equal(mean.view(np.uint32), om.view(np.uint32))
