@@ -110,6 +110,7 @@ struct mi_ctx {
     int refill_primary = 12;    // MI_TRACER_REFILL_PRIMARY: the same at level 0, where a refill only reads parked camera rays
     int leaf_min = 16;          // MI_TRACER_LEAF_MIN: lanes with a pending leaf that trigger a leaf phase
     int tail_refill = 16;       // MI_TRACER_TAIL_REFILL: idle lanes that trigger a refill in k_tail
+    int64_t batch_budget = (int64_t)32 << 30; // bytes of path state per batch and stream: min(total / 4, 2/5 of the free) of the device's memory at mi_ctx_create (MI_TRACER_BATCH_GB)
     int shade_min = 24;         // MI_TRACER_SHADE_MIN: lanes waiting to be shaded that trigger a shade phase of k_tail
     int shade_wg_per_cu = 8;    // MI_TRACER_SHADE_WG_PER_CU: workgroups of k_shade per CU (grid-stride loop)
     int tail_wg_per_cu = 4;     // workgroups of k_tail resident per CU (occupancy query at context creation)
@@ -163,6 +164,13 @@ MI_API mi_status mi_ctx_create(int device_id, mi_ctx **out) {
     c->leaf_min = env_int("MI_TRACER_LEAF_MIN", 1, 64, c->leaf_min);
     c->shade_min = env_int("MI_TRACER_SHADE_MIN", 1, 64, c->shade_min);
     c->tail_refill = env_int("MI_TRACER_TAIL_REFILL", 1, 64, c->tail_refill);
+    {
+        size_t mem_free = 0, mem_total = 0;
+        if (hipMemGetInfo(&mem_free, &mem_total) == hipSuccess && mem_total > 0)
+            c->batch_budget = std::max<int64_t>((int64_t)1 << 30, (int64_t)std::min(mem_total / 4, mem_free * 2 / 5));
+        const int gb = env_int("MI_TRACER_BATCH_GB", 0, 1 << 16, 0);
+        if (gb > 0) c->batch_budget = (int64_t)gb << 30;
+    }
     c->tail_threshold = env_int("MI_TRACER_TAIL", 0, 1 << 30, c->tail_threshold);
     // k_shade walks its stream with a grid-stride loop: a grid that is a multiple of what is resident
     // at once keeps the last round full (8 per CU against 5 resident measured 9 % slower than 5 or 10)
@@ -1132,10 +1140,12 @@ MI_API mi_status mi_render_device(mi_ctx *c, const mi_render_params *p, void *d_
     hipStream_t st = stream_v ? (hipStream_t)stream_v : c->stream;
     const int64_t local = shard_pixels(g);
     const int spp = g.samples * g.samples;
-    // default batch: 64 Mi path slots, fewer for deep paths so that the per-batch state (32 B of history per
-    // level, two ray streams, hits, path values: ~128 B + 32 B per level and slot) stays below ~32 GB
+    // default batch: as many path slots as a quarter of the GPU's memory holds (there are two sets of path state, one
+    // per stream), at most 256 Mi: per slot two ray streams, hits, a path value (~128 B) and 32 B of history per level.
+    // 288 GB of HBM are there to be used: the fewer batches a frame has, the fewer sparse tails it pays (C4, 2.1 G
+    // paths: 64 Mi slots per batch 8990 Mrays/s, 128 Mi 9265, 256 Mi 9511).
     const int64_t per_slot = 128 + 32 * (int64_t)std::max(1, p->depth + 1);
-    int64_t want = p->batch_paths > 0 ? p->batch_paths : std::min<int64_t>((int64_t)64 << 20, std::max<int64_t>((int64_t)1 << 20, ((int64_t)32 << 30) / per_slot));
+    int64_t want = p->batch_paths > 0 ? p->batch_paths : std::min<int64_t>((int64_t)256 << 20, std::max<int64_t>((int64_t)1 << 20, c->batch_budget / per_slot));
     want = std::min<int64_t>(want, (int64_t)1 << 30);
     int64_t npix_b = std::max<int64_t>(64, want / spp / 64 * 64);
     npix_b = std::min(npix_b, std::max<int64_t>(local, 1));
