@@ -111,7 +111,9 @@ typedef struct mi_render_params {
     int32_t tile_h;
     int32_t shard_rank;   /* this context renders tiles k with k % shard_count ==   */
     int32_t shard_count;  /*   shard_rank (row-major tile index); 0/1 -> everything */
-    int64_t batch_paths;  /* max paths in flight per wavefront batch; 0 -> default  */
+    int64_t batch_paths;  /* max paths in flight per wavefront batch; 0 -> default:
+                             what a quarter of the GPU's memory holds, at most 256 Mi;
+                             the batches of a frame are made equal in size          */
     int32_t count_work;   /* != 0: run the instrumented extend kernel that counts node
                              visits and primitive tests (slower; for roofline
                              accounting, never inside a timed region)                */
