@@ -1658,13 +1658,18 @@ MI_API mi_status mi_group_render(mi_group *g, const mi_render_params *p, uint8_t
     HIPCHK(hipSetDevice(g->devices[0]));
     HIPCHK(hipMemcpyAsync(g->gathered.p, g->rgba8[0].p, bytes, hipMemcpyDeviceToDevice, g->ctx[0]->stream));
     NCCLCHK(g_rccl.GroupStart());
-    for (int k = 1; k < n; k++) {
-        HIPCHK(hipSetDevice(g->devices[k]));
-        NCCLCHK(g_rccl.Send(g->rgba8[k].p, bytes, ncclUint8, 0, g->comms[k], g->ctx[k]->stream));
-        HIPCHK(hipSetDevice(g->devices[0]));
-        NCCLCHK(g_rccl.Recv((char *)g->gathered.p + (size_t)k * bytes, bytes, ncclUint8, k, g->comms[0], g->ctx[0]->stream));
+    ncclResult_t xr = ncclSuccess; // a call that fails inside the group must not leave the group open
+    hipError_t xe = hipSuccess;
+    for (int k = 1; k < n && xr == ncclSuccess && xe == hipSuccess; k++) {
+        if ((xe = hipSetDevice(g->devices[k])) != hipSuccess) break;
+        if ((xr = g_rccl.Send(g->rgba8[k].p, bytes, ncclUint8, 0, g->comms[k], g->ctx[k]->stream)) != ncclSuccess) break;
+        if ((xe = hipSetDevice(g->devices[0])) != hipSuccess) break;
+        xr = g_rccl.Recv((char *)g->gathered.p + (size_t)k * bytes, bytes, ncclUint8, k, g->comms[0], g->ctx[0]->stream);
     }
-    NCCLCHK(g_rccl.GroupEnd());
+    const ncclResult_t ge = g_rccl.GroupEnd();
+    if (xe != hipSuccess) return fail(MI_ERR_HIP, "mi_group_render: hipSetDevice failed in the exchange: %s", hipGetErrorString(xe));
+    if (xr != ncclSuccess) return fail(MI_ERR_HIP, "mi_group_render: ncclSend/ncclRecv failed: %s", g_rccl.GetErrorString(xr));
+    NCCLCHK(ge);
     for (int k = 1; k < n; k++) { // the senders' buffers are free again when their streams are done
         HIPCHK(hipSetDevice(g->devices[k]));
         HIPCHK(hipStreamSynchronize(g->ctx[k]->stream));
