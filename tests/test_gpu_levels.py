@@ -109,3 +109,20 @@ def test_tail_grid_larger_than_the_extend_grid_with_deep_stacks():
         assert st.rays_cast == cnt.rays and st.rays_cast > 3 * st.paths     # the paths really go deep
         assert st.rays_extend == st.paths                                   # level >= 1 ran in k_tail
         assert same(mean, omean) and np.array_equal(rgb, orgb)
+
+
+def test_small_memory_budget_cuts_frames_into_equal_batches(ctx, scenes_small):
+    # MI_TRACER_BATCH_GB=1: 3.3 M path slots per batch at depth 5.  Frames of 2, 3 (made 4 for the two streams) and 5
+    # default-sized batches must equal the one-batch render of the default context, ray for ray.
+    sc = scenes_small["blob3"]
+    ctx.upload(sc)
+    with fresh_context(MI_TRACER_BATCH_GB=1) as small:
+        small.upload(sc)
+        for width, s, want_batches in ((1600, 2, 2), (1920, 2, 4), (1600, 3, 4), (1920, 3, 6)):
+            w, h = sc.image_size(width)
+            p = P.Context.params(w, h, s, 5, seed=2)
+            mean, rgb, st = ctx.render(p)
+            mean_s, rgb_s, st_s = small.render(p)
+            assert st_s.batches == want_batches and st.batches <= 2, (width, s, st_s.batches, st.batches)
+            assert st_s.rays_cast == st.rays_cast and st_s.paths == st.paths
+            assert np.array_equal(rgb_s, rgb) and same(mean_s, mean)
