@@ -1,7 +1,8 @@
 """The per-level secondary kernels under test at every size.
 
-By default k_tail takes over a batch once a level holds <= 1.5 M rays (MI_TRACER_TAIL), so in every small
-test the levels >= 1 never reach k_extend<false,false> / k_shade<false>.  This module repeats the parity,
+By default k_tail takes over a batch once a level holds at most 200-700 k rays (1/40 of the batch's paths;
+MI_TRACER_TAIL sets a fixed number), so in every small test the levels >= 1 never reach k_extend<false,false> /
+k_shade<false>.  This module repeats the parity,
 golden and fuzz comparisons in contexts of their own (the tuning environment is read in mi_ctx_create):
   MI_TRACER_TAIL=0     every level through the per-level kernels (sub-streams, segcap arithmetic,
                        k_shade<false> compaction), k_tail never runs;
@@ -101,7 +102,7 @@ def test_tail_grid_larger_than_the_extend_grid_with_deep_stacks():
 
     class Fake:  # the oracle binding only needs .soa
         soa = C.pointer(s)
-    with fresh_context(MI_TRACER_TAIL_WG_PER_CU=16) as c:
+    with fresh_context(MI_TRACER_TAIL_WG_PER_CU=16, MI_TRACER_TAIL=700000) as c:  # an explicit threshold: every level >= 1 of this frame in k_tail
         N.check(N.mi.mi_scene_upload(c._h, C.byref(s)))
         p = P.Context.params(768, 768, 1, 8, seed=1)
         mean, rgb, st = c.render(p)
