@@ -31,8 +31,8 @@ def test_c4_bands_and_primary_hits_match_the_oracle(ctx, blob8):
     p = P.Context.params(w, h, S, D, seed=0)
     mean, rgb, st = ctx.render(p)
     assert st.paths == w * h * S * S and st.batches >= 4   # default batch: a quarter of the GPU's memory per stream, at most 256 Mi slots
-    for y0 in (400, 1079, 1700):          # below, across and above the object's silhouette
-        om, orgb, _ = O.render(sc, p, rows=(y0, y0 + 2))
+    for y0 in (3, 400, 771, 1079, 1290, 1500, 1700, 2156):   # eight two-row bands over the frame: ground, silhouette, object, sky
+        om, orgb, _ = O.render(sc, p, threads=16, rows=(y0, y0 + 2))
         assert np.array_equal(rgb[y0:y0 + 2], orgb[y0:y0 + 2]), y0
         assert same(mean[y0:y0 + 2], om[y0:y0 + 2]), y0
     # primary hits of a strided set of pixels (1 sample per pixel) against the oracle's tree walk with the canonical
@@ -65,6 +65,27 @@ def test_c4_bands_and_primary_hits_match_the_oracle(ctx, blob8):
         _, rgb_b, st_b = ctx.render(P.Context.params(w, h, S, D, seed=0, batch_paths=bp), want_mean=False)
         assert st_b.rays_cast == st.rays_cast and st_b.batches > st.batches
         assert np.array_equal(rgb_b, rgb)
+
+    # C4's defining property — the frame tile-sharded over 2/4/8 GPUs (BASELINE configs[3]): the eight shards (r, 8)
+    # rendered one after the other on this GPU into a "gathered" buffer, assembled by mi_assemble_rgb8_device
+    # (what rank 0 does after the RCCL gather), must be the single-GPU frame byte for byte, with the rays conserved
+    import torch
+    n_sh = 8
+    stride = P.shard_pixels(P.Context.params(w, h, S, D, seed=0, shard=(0, n_sh)))
+    gathered = torch.zeros(n_sh * stride * 4, dtype=torch.uint8, device="cuda:0")
+    frame = torch.full((h * w * 3,), 77, dtype=torch.uint8, device="cuda:0")
+    sh_rays = sh_paths = 0
+    for r in range(n_sh):
+        pr = P.Context.params(w, h, S, D, seed=0, shard=(r, n_sh))
+        assert P.shard_pixels(pr) <= stride
+        st_r = ctx.render_device(pr, None, gathered.data_ptr() + r * stride * 4)
+        sh_rays += st_r.rays_cast
+        sh_paths += st_r.paths
+    ctx.assemble_rgb8_device(P.Context.params(w, h, S, D, seed=0, shard=(0, n_sh)), gathered.data_ptr(), stride, frame.data_ptr())
+    torch.cuda.synchronize()
+    assert sh_rays == st.rays_cast and sh_paths == st.paths
+    assert np.array_equal(frame.cpu().numpy().reshape(h, w, 3), rgb)
+    del gathered, frame
 
     # device-built tree (PLOC, ~28 levels): same frame, same ray count, same primary hits
     b = ctx.upload_build(sc)

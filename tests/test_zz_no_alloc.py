@@ -1,7 +1,9 @@
 """mi_render_device_noalloc — the one entry point that allocates nothing (static 64-MiB workspace) — against
 mi_render_device, through the C-ABI, bit for bit: two calls in a row, the second with a smaller input (it finds
 the first call's contents in the workspace), single- and multi-batch frames, the enqueue-only mode, a device-built
-tree, a shard, and the rejection of inputs whose smallest batch does not fit."""
+tree, a shard, and the rejection of inputs whose smallest batch does not fit.  Its defining contract — no allocation,
+usable under HIP graph capture — is exercised too: free device memory is unchanged across the calls, and the
+enqueue-only mode is captured into a graph (capture fails on any allocation or synchronisation) and replayed twice."""
 import ctypes as C
 
 import numpy as np
@@ -77,3 +79,43 @@ def test_noalloc_rejects_what_cannot_fit(ctx, scenes_small):
     assert N.mi.mi_render_device_noalloc(ctx._h, C.byref(pc), None, out.data_ptr(), None, None) == N.MI_ERR_INVALID
     # and the regular entry point still takes it
     ctx.render(P.Context.params(16, 16, 2, 1))
+
+
+def test_noalloc_allocates_nothing_and_runs_under_graph_capture(ctx, scenes_small):
+    sc = scenes_small["cornell"]
+    ctx.upload(sc)
+    w, h = sc.image_size(160)
+    p = P.Context.params(w, h, 2, 5, seed=21)
+    n = P.shard_pixels(p)
+    dev = torch.device("cuda", 0)
+    want_mean = torch.zeros((n, 4), dtype=torch.float32, device=dev)
+    want_rgba = torch.zeros((n, 4), dtype=torch.uint8, device=dev)
+    ctx.render_device(p, want_mean.data_ptr(), want_rgba.data_ptr())
+    mean = torch.zeros((n, 4), dtype=torch.float32, device=dev)
+    rgba = torch.zeros((n, 4), dtype=torch.uint8, device=dev)
+    side = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(side):                                       # the runtime backs a new stream with a hardware queue on first use
+        rgba.zero_()
+    torch.cuda.synchronize()
+    # (1) hipMemGetInfo before and after: nothing was allocated or freed on the device, with stats and without
+    free0, _ = torch.cuda.mem_get_info(dev)
+    s1 = ctx.render_device_noalloc(p, mean.data_ptr(), rgba.data_ptr(), None, True)
+    ctx.render_device_noalloc(p, mean.data_ptr(), rgba.data_ptr(), side.cuda_stream, False)
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info(dev)
+    assert free1 == free0, (free0, free1)
+    assert s1.batches >= 1 and torch.equal(rgba, want_rgba) and torch.equal(mean.view(torch.int32), want_mean.view(torch.int32))
+    # (2) the enqueue-only mode (stats == NULL) inside a stream capture; the graph replayed twice
+    mean.zero_(); rgba.zero_()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        ctx.render_device_noalloc(p, mean.data_ptr(), rgba.data_ptr(), torch.cuda.current_stream().cuda_stream, False)
+    torch.cuda.synchronize()
+    assert int(rgba.sum().item()) == 0                                  # capture enqueued nothing
+    for _ in range(2):
+        mean.zero_(); rgba.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(rgba, want_rgba) and torch.equal(mean.view(torch.int32), want_mean.view(torch.int32))
+    del g
