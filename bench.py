@@ -254,7 +254,10 @@ def main():
         extend_s_per_step = s_ms_ext / serial_steps * 1e-3
         algorithmic_gbs = bytes_per_ray * rays_rank0_per_step / extend_s_per_step / 1e9 if extend_s_per_step > 0 else 0.0
         valu_tflops = flops_per_ray * rays_rank0_per_step / extend_s_per_step / 1e12 if extend_s_per_step > 0 else 0.0
-        pmc = pmc_record(args.workload, world, args.bvh)
+        frame_rays = stc.rays_cast if world == 1 else None      # N > 1: a rank's shard is scaled below; the source hash still binds
+        pmc, pmc_stale = pmc_record(args.workload, world, args.bvh, frame_rays)
+        if pmc and pmc.get("abi_version") not in (None, P._native.mi.mi_abi_version()):
+            pmc, pmc_stale = None, f"{pmc.get('source')}: ABI {pmc.get('abi_version')}, this library {P._native.mi.mi_abi_version()}"
         roof = {"bound": "valu_issue", "kernel": "k_extend", "achieved": None, "peak": VALU_PEAK_TLANEOPS, "unit": "Tlane-op/s", "frac": None,
                 "traffic": None, "avg_launch_ms": avg_launch_ms, "launches_per_step": launches_per_step,
                 "extend_ms_per_step": extend_s_per_step * 1e3, "serial_ms_per_step": s_ms_tot / serial_steps, "serial_steps": serial_steps,
@@ -292,7 +295,7 @@ def main():
             # per k_extend launch, like `achieved`: counters of the launches that did work / launches per frame
             n_l = max(1, pmc.get("extend_launches_per_frame", launches_per_step))
             lane_ops_per_s = ke["lane_ops_sum"] / extend_s_per_step if extend_s_per_step > 0 else 0.0
-            roof.update({"achieved": lane_ops_per_s / 1e12, "frac": lane_ops_per_s / 1e12 / VALU_PEAK_TLANEOPS,
+            roof.update({"pmc_stale": False, "achieved": lane_ops_per_s / 1e12, "frac": lane_ops_per_s / 1e12 / VALU_PEAK_TLANEOPS,
                          "traffic": ke["hbm_bytes_sum"] / n_l,
                          "frac_4cycle_slots": ke["useful_lane_slots_4cyc"], "valu_inst_rate_4cycle": ke["valu_inst_rate"],
                          "lanes_active_of_64": ke["lanes_active"],
@@ -306,6 +309,10 @@ def main():
                          "pmc": {"source": pmc["source"], "k_extend_by_level": ke["by_level"],
                                  "k_shade": {k: v for k, v in (pmc.get("k_shade") or {}).items() if k != "by_level"},
                                  "k_tail": {k: v for k, v in (pmc.get("k_tail") or {}).items() if k != "by_level"}}})
+        elif pmc_stale:
+            roof["pmc_stale"] = True
+            roof["pmc"] = {"source": None, "stale": pmc_stale, "note": "the committed PMC pass does not describe the kernels being timed: achieved / frac / traffic "
+                           "are withheld; run profiles/tools/collect.sh on this tree"}
         else:
             roof["pmc"] = {"source": None, "note": f"no PMC pass on file for workload {args.workload} / bvh {args.bvh} / {world} rank(s): run profiles/tools/collect.sh"}
         out = {
@@ -346,6 +353,11 @@ def main():
                                         "what": "mi_render with the RGB8 frame copied to a pageable host buffer (what HipTracer::traceImage calls), PCIe-inclusive"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"], band = cpu_baseline(scene, w, h, samples, depth, args.cpu_seconds)
+            # SURVEY 8(d) "B2": what a user of the reference's own CpuTracer gets on a mesh of this class — its source cannot
+            # travel to the GPU box, so the figure is the survey container's, quoted and labelled as such
+            out["cpu_baseline"]["reference_as_shipped"] = {
+                "value": 0.060, "unit": "Mrays/s/thread", "where": "survey container, 8 vCPU, g++ -O2, primary rays 640x360 on the 81,933-primitive mesh, "
+                "reference BVH (genCluster, bvh.cu:66-145)", "src": "SURVEY.md section 6 / 8(d) B2 [measured there, not on this box]"}
             # second half of the metric ("RMSE vs CpuTracer"): the rows the oracle has just rendered against the
             # same rows of a GPU frame (raycheck's RMS over uint8 RGB, float subtraction); outside the timed region
             y0, y1, omean, orgb = band
@@ -366,16 +378,42 @@ def main():
         dist.destroy_process_group()
 
 
-def pmc_record(workload, world, bvh):
+KERNEL_SOURCES = ("pathtracer_amd/csrc/mi_kernels.h", "pathtracer_amd/csrc/mi_tracer.hip", "pathtracer_amd/csrc/mi_bvh_build.h")
+
+
+def kernel_source_sha256(root=ROOT):
+    """sha256 over the device sources the render kernels are compiled from, in KERNEL_SOURCES order.  pmc_to_json.py
+    stores it with every PMC pass; pmc_record() recomputes it, so counters of OTHER code are never divided by this
+    code's time."""
+    import hashlib
+    h = hashlib.sha256()
+    for rel in KERNEL_SOURCES:
+        with open(os.path.join(root, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def pmc_record(workload, world, bvh, rays_cast_frame=None, root=ROOT):
     """Counter-derived figures of the render kernels for this workload from the PMC passes committed under profiles/
     (profiles/roofline_pmc.json, written by profiles/tools/pmc_to_json.py from raw rocprofv3 --pmc output; host-built
-    tree, the whole frame on one GPU — the caller scales it for a shard).  None if this workload was not profiled."""
-    path = os.path.join(ROOT, "profiles", "roofline_pmc.json")
+    tree, the whole frame on one GPU — the caller scales it for a shard).  Returns (record | None, why_stale | None):
+    the record is refused — and the roofline's counter-derived fields stay null, with `pmc_stale: true` — when the
+    pass was taken from other kernel sources than the ones in this tree (sha256, kernel_source_sha256), with another
+    ABI version, or when the frame it profiled cast another number of rays than this run's frame (other tuning
+    knobs, batch sizes or scene)."""
+    path = os.path.join(root, "profiles", "roofline_pmc.json")
     if bvh != "host" or not os.path.exists(path):
-        return None
+        return None, None
     with open(path) as f:
         rec = json.load(f).get(workload)
-    return rec if rec and rec.get("k_extend") else None
+    if not (rec and rec.get("k_extend")):
+        return None, None
+    live = kernel_source_sha256(root)
+    if rec.get("kernel_source_sha256") != live:
+        return None, f"{rec.get('source')}: taken from kernel sources {str(rec.get('kernel_source_sha256'))[:16]}, this tree has {live[:16]}"
+    if rays_cast_frame is not None and rec.get("rays_cast_frame") and int(rec["rays_cast_frame"]) != int(rays_cast_frame):
+        return None, f"{rec.get('source')}: its frame cast {rec['rays_cast_frame']} rays, this run's frame {int(rays_cast_frame)}"
+    return rec, None
 
 
 def cpu_baseline(scene, w, h, samples, depth, budget_s):

@@ -248,7 +248,14 @@ mi_status mi_render_device(mi_ctx *ctx, const mi_render_params *params,
  * Every context on a GPU shares that GPU's array, and a call finds the previous call's contents in it
  * (what must start at zero is cleared on the stream): calls that overlap on one GPU — two contexts, two
  * streams, or a call made while an un-synchronised earlier one is still running on another stream —
- * RACE.  Calls on the same stream are ordered and safe. */
+ * RACE.  Calls on the same stream are ordered and safe.
+ * Lifetime: the enqueued kernels read the context's scene until they have run.  mi_ctx_destroy, mi_scene_upload,
+ * mi_scene_upload_build and mi_cubemap_upload therefore wait for the whole DEVICE (hipDeviceSynchronize) before
+ * they release or replace anything — never call them between hipStreamBeginCapture and hipStreamEndCapture, and
+ * do not launch a captured graph of this call after its context was destroyed or its scene replaced.
+ * Verified under capture: tests/test_zz_no_alloc.py captures the stats == NULL mode with hipStreamBeginCapture
+ * (torch.cuda.graph), replays the graph twice and compares with mi_render_device; C3 at 1080p through this entry
+ * point: see DESIGN.md ("The entry point that allocates nothing"). */
 mi_status mi_render_device_noalloc(mi_ctx *ctx, const mi_render_params *params,
                                    void *d_rgba_mean, void *d_rgba8, void *stream,
                                    mi_stats *stats);

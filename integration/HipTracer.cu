@@ -132,9 +132,20 @@ bool HipTracer::uploadCubeMap() {
 
 void HipTracer::traceImage(int w, int h) {
     if (!ctx) return;
-    if (uploaded != scene) {                      // once per scene; the reference re-clones on every call (GpuTracer.cu:173)
-        if (!flatten() || !uploadCubeMap()) return;
-        uploaded = scene;
+    if (worker.joinable()) worker.join();         // a second traceImage without waitRender: assigning over a joinable thread terminates
+    // Once per scene; the reference re-clones on every call (GpuTracer.cu:173).  Tracer::loadScene is not virtual, so a
+    // reload is recognised here: the cache is keyed on the Scene, its BVH root and its primitive count (loadScene leaks
+    // the old Scene, tracer.cu:62, so its address is not reused; the other two keys guard a build that frees it).
+    const void *root_now = scene ? (const void *)scene->bvh.root : nullptr;
+    const size_t prims_now = scene ? scene->actual.size() : 0;
+    if (uploaded != scene || uploaded_root != root_now || uploaded_prims != prims_now) {
+        if (!flatten()) return;
+        uploaded = scene; uploaded_root = root_now; uploaded_prims = prims_now;
+        uploaded_cube = nullptr; cube_valid = false;
+    }
+    if (!cube_valid || uploaded_cube != (const void *)cubeMap) {   // the cubemap has its own key: the UI may set it after the scene
+        if (!uploadCubeMap()) return;
+        uploaded_cube = (const void *)cubeMap; cube_valid = true;
     }
     worker = std::thread([this, w, h] {
         mi_render_params p{};

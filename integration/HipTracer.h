@@ -43,7 +43,11 @@ private:
     mi_scene_soa soa{};
     mi_stats stats{};
     unsigned long long seed = 0;
-    const Scene *uploaded = nullptr;          // the scene resident on the device
+    const Scene *uploaded = nullptr;          // the scene resident on the device, with what else identifies it
+    const void *uploaded_root = nullptr;
+    size_t uploaded_prims = 0;
+    const void *uploaded_cube = nullptr;      // the CubeMap resident on the device (nullptr + cube_valid: white background)
+    bool cube_valid = false;
     std::thread worker;
     // storage behind the borrowed pointers of `soa`
     std::vector<float> nodes, tri_v0, tri_uinv, tri_vinv, tri_ninv, tri_normal, sph, mats;

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <initializer_list>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -34,6 +35,49 @@ static mi_status fail(mi_status st, const char *fmt, ...) {
             return fail(e_ == hipErrorOutOfMemory ? MI_ERR_OOM : MI_ERR_HIP, "%s failed: %s (%s:%d)", #call, \
                         hipGetErrorString(e_), __FILE__, __LINE__);                                        \
     } while (0)
+
+// ---- profiler stage ranges (the reference brackets its render with cudaProfilerStart/Stop, GpuTracer.cu:162,183) ----
+// With MI_TRACER_ROCTX (or MI_TRACER_DEBUG_LEVELS) set, every frame, batch and level of the wavefront loop is a
+// roctx range ("mi_render" > "batch b" > "level k"), so `rocprofv3 --marker-trace --kernel-trace` attributes the
+// launches (k_tail | k_extend | k_shade per level) to their batch and bounce level.  The library is loaded on first
+// use (librocprofiler-sdk-roctx, else the older libroctx64); without it, or without the variable, nothing happens.
+#include <dlfcn.h>
+namespace {
+struct Roctx {
+    int (*push)(const char *) = nullptr;
+    int (*pop)() = nullptr;
+    bool tried = false;
+};
+Roctx g_roctx;
+std::mutex g_roctx_mutex;
+bool roctx_on() {
+    if (!getenv("MI_TRACER_ROCTX") && !getenv("MI_TRACER_DEBUG_LEVELS")) return false;
+    std::lock_guard<std::mutex> lock(g_roctx_mutex);
+    if (!g_roctx.tried) {
+        g_roctx.tried = true;
+        for (const char *n : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
+            void *h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+            if (!h) continue;
+            g_roctx.push = (int (*)(const char *))dlsym(h, "roctxRangePushA");
+            g_roctx.pop = (int (*)())dlsym(h, "roctxRangePop");
+            if (g_roctx.push && g_roctx.pop) break;
+            g_roctx.push = nullptr; g_roctx.pop = nullptr;
+            dlclose(h);
+        }
+    }
+    return g_roctx.push != nullptr;
+}
+struct RoctxRange { // RAII: a range around a scope, when ranges are on
+    bool on;
+    RoctxRange(bool enabled, const char *fmt, long long a = 0) : on(enabled) {
+        if (!on) return;
+        char name[64];
+        snprintf(name, sizeof name, fmt, a);
+        g_roctx.push(name);
+    }
+    ~RoctxRange() { if (on) g_roctx.pop(); }
+};
+} // namespace
 
 // ---- workspace of the entry point that allocates nothing (mi_render_device_noalloc) ---------------------
 // All per-batch path state (ray streams, hits, history, path values, counters, overflow stacks, totals) in ONE
@@ -232,7 +276,9 @@ MI_API mi_status mi_ctx_create(int device_id, mi_ctx **out) {
 MI_API void mi_ctx_destroy(mi_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    // Everything that may still read this context's buffers must be done before they are released: its own two
+    // streams, and the caller's stream of an enqueue-only mi_render_device_noalloc (include/mi_tracer.h: lifetime).
+    (void)hipDeviceSynchronize();
     DevBuf *all[] = {&c->nodes, &c->nodes4, &c->qnodes, &c->tri, &c->tri_normal, &c->tri_mat, &c->tri_has_vmat, &c->tri_shade, &c->sph, &c->sph_mat, &c->mats,
                      &c->prim_id, &c->cube, &c->out_mean, &c->out_rgba8,
                      &c->out_rgb8, &c->out_mean_frame, &c->probe_i, &c->probe_t, &c->probe_n};
@@ -244,7 +290,6 @@ MI_API void mi_ctx_destroy(mi_ctx *c) {
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     if (c->h_totals) (void)hipHostFree(c->h_totals);
     (void)hipStreamDestroy(c->stream);
-    (void)hipStreamSynchronize(c->stream2);
     (void)hipStreamDestroy(c->stream2);
     (void)hipEventDestroy(c->ev_fork);
     (void)hipEventDestroy(c->ev_join);
@@ -520,6 +565,7 @@ MI_API mi_status mi_scene_upload(mi_ctx *c, const mi_scene_soa *s) {
     mi_status vs = validate_scene(s, &depth2);
     if (vs != MI_OK) return vs;
     HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipDeviceSynchronize()); // kernels an enqueue-only render left on a caller's stream may still read the scene about to be replaced
     HIPCHK(c->nodes.ensure(std::max<size_t>((size_t)s->n_nodes * 64, 16)));
     if (s->n_nodes) HIPCHK(hipMemcpy(c->nodes.p, s->nodes, (size_t)s->n_nodes * 64, hipMemcpyHostToDevice));
     mi_status us = upload_prims(c, s);
@@ -617,6 +663,7 @@ MI_API mi_status mi_scene_upload_build(mi_ctx *c, const mi_scene_soa *s, const f
     for (size_t i = 0; i < 4 * (size_t)s->n_sph; i++)
         if (!(s->sph_center_radius[i] > -1e15f && s->sph_center_radius[i] < 1e15f)) return fail(MI_ERR_INVALID, "scene: non-finite or huge sphere");
     HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipDeviceSynchronize()); // as in mi_scene_upload
     mi_status us = upload_prims(c, s);
     if (us != MI_OK) return us;
     c->sc.qnodes = nullptr;
@@ -1050,11 +1097,17 @@ static mi_status render_batches(mi_ctx *c, const mi_render_params *p, const Shar
         hipLaunchKernelGGL(k_sum_counts, dim3(1), dim3(64), 0, bs, m.counters, levels, m.totals, m.counters + (kMaxLevels + 1) * kLevelWords);
     };
     const size_t evi = 2 + (size_t)n_batches * levels * 4;
+    const bool ranges = roctx_on();
+    RoctxRange frame_range(ranges, "mi_render");
     for (int64_t b = 0; b < n_batches; b++) {
         Batch B;
         if (!batch_of(b, B)) return fail(MI_ERR_INVALID, "internal: division constants failed their check");
+        RoctxRange batch_range(ranges, "batch %lld", (long long)b);
         HIPCHK(begin(b));
-        for (int k = 0; k < levels; k++) HIPCHK(level(b, B, k));
+        for (int k = 0; k < levels; k++) {
+            RoctxRange level_range(ranges, "level %lld", (long long)k);
+            HIPCHK(level(b, B, k));
+        }
         end(b, B);
     }
     HIPCHK(hipGetLastError());
@@ -1170,23 +1223,41 @@ MI_API mi_status mi_render_device(mi_ctx *c, const mi_render_params *p, void *d_
         if (half * spp >= c->split_min && half < local) npix_b = half;
         else n_sets = 1;
     }
+    // The batch size above comes from the memory that was free when the context was created (batch_budget); other
+    // contexts, or a host framework that allocated since, may have taken it.  A hipErrorOutOfMemory while the path
+    // state grows is therefore not an error yet: both sets are released, the batch is halved and planned again, down
+    // to 64 pixels; only then MI_ERR_OOM.
     BatchPlan bp;
-    mi_status ps = plan_batch(c, npix_b, spp, p->depth, bp);
-    if (ps != MI_OK) return ps;
     PathMem sets[2];
+    for (;;) {
+        mi_status ps = plan_batch(c, npix_b, spp, p->depth, bp);
+        if (ps != MI_OK) return ps;
+        hipError_t ae = hipSuccess;
+        auto grow = [&](DevBuf &b, size_t bytes) { if (ae == hipSuccess) ae = b.ensure(bytes); };
+        for (int s = 0; s < n_sets; s++) {
+            auto &pb = c->pb[s];
+            for (int i = 0; i < 2; i++) { grow(pb.ray_o[i], bp.stream_cap * 16); grow(pb.ray_d[i], bp.stream_cap * 16); grow(pb.thr[i], bp.stream_cap * 16); }
+            grow(pb.hits, bp.stream_cap * 8);
+            grow(pb.path_out, bp.cap * 16);
+            grow(pb.hist, bp.cap * 32 * bp.hist_levels);
+            grow(pb.counters, kCounterWords * 4);
+            grow(pb.ovf, stack_bytes(c));
+            grow(pb.totals, kTotals * 8);
+        }
+        if (ae == hipSuccess) break;
+        if (ae != hipErrorOutOfMemory) HIPCHK(ae);
+        (void)hipGetLastError(); // the failed hipMalloc's sticky error
+        HIPCHK(hipStreamSynchronize(c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream2));
+        for (auto &pb : c->pb) {
+            DevBuf *set[] = {&pb.ray_o[0], &pb.ray_o[1], &pb.ray_d[0], &pb.ray_d[1], &pb.thr[0], &pb.thr[1], &pb.hits, &pb.path_out, &pb.hist};
+            for (DevBuf *b : set) b->release();
+        }
+        if (npix_b <= 64) return fail(MI_ERR_OOM, "mi_render_device: no device memory for the path state of a 64-pixel batch");
+        npix_b = std::max<int64_t>(64, npix_b / 2 / 64 * 64);
+    }
     for (int s = 0; s < n_sets; s++) {
         auto &pb = c->pb[s];
-        for (int i = 0; i < 2; i++) {
-            HIPCHK(pb.ray_o[i].ensure(bp.stream_cap * 16));
-            HIPCHK(pb.ray_d[i].ensure(bp.stream_cap * 16));
-            HIPCHK(pb.thr[i].ensure(bp.stream_cap * 16));
-        }
-        HIPCHK(pb.hits.ensure(bp.stream_cap * 8));
-        HIPCHK(pb.path_out.ensure(bp.cap * 16));
-        HIPCHK(pb.hist.ensure(bp.cap * 32 * bp.hist_levels));
-        HIPCHK(pb.counters.ensure(kCounterWords * 4));
-        HIPCHK(pb.ovf.ensure(stack_bytes(c)));
-        HIPCHK(pb.totals.ensure(kTotals * 8));
         PathMem &m = sets[s];
         for (int i = 0; i < 2; i++) { m.ray_o[i] = pb.ray_o[i].as<float4>(); m.ray_d[i] = pb.ray_d[i].as<float4>(); m.thr[i] = pb.thr[i].as<float4>(); }
         m.hits = pb.hits.as<float2>(); m.path_out = pb.path_out.as<float4>(); m.hist = pb.hist.as<float4>();
@@ -1460,7 +1531,7 @@ MI_API mi_status mi_occluded_rays(mi_ctx *c, int64_t total, const float *rays, c
 MI_API mi_status mi_cubemap_upload(mi_ctx *c, const mi_cubemap *cm) {
     if (!c) return fail(MI_ERR_INVALID, "mi_cubemap_upload: ctx is NULL");
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipDeviceSynchronize()); // as in mi_scene_upload
     if (!cm) { // back to the white background of CpuTracer.cu:125
         c->sc.cube = nullptr;
         return MI_OK;

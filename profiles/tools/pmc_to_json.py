@@ -148,7 +148,15 @@ def main():
         json.dump(out, f, indent=1)
     path = os.path.join("profiles", "roofline_pmc.json")
     allw = json.load(open(path)) if os.path.exists(path) else {}
-    allw[workload] = {"tag": tag, "source": f"profiles/{tag}_pmc.json", "extend_launches_per_frame": n_ext, "rays_cast_frame": rays_frame, **{k: v for k, v in out["summary"].items()}}
+    # what ties the counters to the code they were taken from (bench.pmc_record refuses the record on a mismatch)
+    abi = None
+    try:
+        from pathtracer_amd import _native
+        abi = int(_native.mi.mi_abi_version())
+    except Exception:  # noqa: BLE001  (converted on a machine without the library: the source hash still binds)
+        pass
+    allw[workload] = {"tag": tag, "source": f"profiles/{tag}_pmc.json", "kernel_source_sha256": bench.kernel_source_sha256(), "abi_version": abi,
+                      "extend_launches_per_frame": n_ext, "rays_cast_frame": rays_frame, **{k: v for k, v in out["summary"].items()}}
     with open(path, "w") as f:
         json.dump(allw, f, indent=1)
     s = out["summary"]["k_extend"]
