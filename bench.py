@@ -344,13 +344,28 @@ def main():
             # the Tracer boundary hands back HOST bytes (HipTracer::traceImage -> mi_render): the same frame with the RGB8 copy to a
             # pageable host buffer, PCIe-inclusive; never `value`
             pf = P.Context.params(w, h, samples, depth, seed=0, one_stream=args.streams == 1)
-            ctx.render(pf, want_mean=False)
-            t1 = time.perf_counter()
-            rh = 0
-            for _ in range(max(2, args.steps // 2)):
-                rh += ctx.render(pf, want_mean=False)[2].rays_cast
-            out["value_host_output"] = {"value": rh / (time.perf_counter() - t1) / 1e6, "unit": "Mrays/s",
-                                        "what": "mi_render with the RGB8 frame copied to a pageable host buffer (what HipTracer::traceImage calls), PCIe-inclusive"}
+            n_h = max(3, args.steps // 2)
+
+            def host_rate(buf):
+                ctx.render(pf, want_mean=False, rgb_out=buf)
+                t1 = time.perf_counter()
+                rh = 0
+                for _ in range(n_h):
+                    rh += ctx.render(pf, want_mean=False, rgb_out=buf)[2].rays_cast
+                return rh / (time.perf_counter() - t1) / 1e6
+
+            # as the Tracer does it: ONE frame buffer (tracer.cu:87-93), pinned while it lives (pt::HipTracer::bufferChanged ->
+            # mi_host_register), every traceImage renders into it
+            fb = np.zeros((h, w, 3), np.uint8)
+            pageable = host_rate(fb)
+            P.host_register(fb)
+            pinned = host_rate(fb)
+            P.host_unregister(fb)
+            out["value_host_output"] = {"value": pinned, "unit": "Mrays/s", "steps": n_h, "frac_of_value": pinned / (rays_all / dt_max / 1e6),
+                                        "pageable": pageable,
+                                        "what": "mi_render with the RGB8 frame copied to the Tracer's host frame buffer (what HipTracer::traceImage calls), "
+                                                "PCIe-inclusive; `value`: the buffer pinned with mi_host_register, as pt::HipTracer pins it in traceSetup; "
+                                                "`pageable`: the same into an unpinned buffer"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"], band = cpu_baseline(scene, w, h, samples, depth, args.cpu_seconds)
             # SURVEY 8(d) "B2": what a user of the reference's own CpuTracer gets on a mesh of this class — its source cannot

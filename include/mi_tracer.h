@@ -254,7 +254,7 @@ mi_status mi_render_device(mi_ctx *ctx, const mi_render_params *params,
  * they release or replace anything — never call them between hipStreamBeginCapture and hipStreamEndCapture, and
  * do not launch a captured graph of this call after its context was destroyed or its scene replaced.
  * Verified under capture: tests/test_zz_no_alloc.py captures the stats == NULL mode with hipStreamBeginCapture
- * (torch.cuda.graph), replays the graph twice and compares with mi_render_device; C3 at 1080p through this entry
+ * (through the host framework's graph API), replays the graph twice and compares with mi_render_device; C3 at 1080p through this entry
  * point: see DESIGN.md ("The entry point that allocates nothing"). */
 mi_status mi_render_device_noalloc(mi_ctx *ctx, const mi_render_params *params,
                                    void *d_rgba_mean, void *d_rgba8, void *stream,
@@ -263,6 +263,16 @@ mi_status mi_render_device_noalloc(mi_ctx *ctx, const mi_render_params *params,
 /* Size in bytes of the static workspace of mi_render_device_noalloc (per GPU).  No counterpart
  * in the reference. */
 int64_t mi_noalloc_workspace_bytes(void);
+
+/* Pins a host buffer the caller owns and will hand to mi_render / mi_group_render again and again (the Tracer's
+ * RGB8 `buffer`, tracer.h:47 / tracer.cu:87-93), so that the frame is written into it by DMA instead of through the
+ * runtime's staging copies for pageable memory (C3 at 1080p: the 6.2-MB frame costs ~0.5 ms pageable, ~0.15 ms
+ * pinned).  Replaces nothing in the reference (GpuTracer.cu:181 copies w*h float4 to pageable memory and converts on
+ * the host, :186-188).  Process-wide, any device; the buffer must stay allocated until mi_host_unregister(ptr) —
+ * unregister BEFORE freeing or resizing it.  Registering the same (ptr, bytes) twice is a no-op; MI_ERR_HIP if the
+ * runtime refuses (e.g. memory that is already pinned). */
+mi_status mi_host_register(void *ptr, size_t bytes);
+mi_status mi_host_unregister(void *ptr);
 
 /* Number of local pixel slots (owned tiles * tile_w * tile_h) of a shard. */
 int64_t mi_shard_pixels(const mi_render_params *params);

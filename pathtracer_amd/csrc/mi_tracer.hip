@@ -180,8 +180,31 @@ static int extend_grid(const mi_ctx *c) { return c->n_cu * c->extend_wg_per_cu; 
 static int stack_grid(const mi_ctx *c) { return c->n_cu * std::max(c->extend_wg_per_cu, std::max(c->extend_wg_primary, c->tail_wg_per_cu)); }
 static size_t stack_bytes(const mi_ctx *c) { return (size_t)(MI_MAX_STACK - MI_LDS_STACK) * stack_grid(c) * MI_BLOCK * 4; }
 
-MI_API int mi_abi_version(void) { return 12; }
+MI_API int mi_abi_version(void) { return 13; }
 MI_API const char *mi_last_error(void) { return g_err.c_str(); }
+
+// Pinned caller buffers (process-wide; hipHostRegisterPortable: every device's DMA engines may write them).
+static std::mutex g_pin_mutex;
+static std::vector<std::pair<void *, size_t>> g_pinned;
+MI_API mi_status mi_host_register(void *ptr, size_t bytes) {
+    if (!ptr || bytes == 0) return fail(MI_ERR_INVALID, "mi_host_register: empty buffer");
+    std::lock_guard<std::mutex> lock(g_pin_mutex);
+    for (auto &q : g_pinned)
+        if (q.first == ptr) return q.second == bytes ? MI_OK : fail(MI_ERR_INVALID, "mi_host_register: %p is registered with another size", ptr);
+    HIPCHK(hipHostRegister(ptr, bytes, hipHostRegisterPortable));
+    g_pinned.push_back({ptr, bytes});
+    return MI_OK;
+}
+MI_API mi_status mi_host_unregister(void *ptr) {
+    std::lock_guard<std::mutex> lock(g_pin_mutex);
+    for (size_t i = 0; i < g_pinned.size(); i++)
+        if (g_pinned[i].first == ptr) {
+            g_pinned.erase(g_pinned.begin() + (long)i);
+            HIPCHK(hipHostUnregister(ptr));
+            return MI_OK;
+        }
+    return fail(MI_ERR_INVALID, "mi_host_unregister: %p was not registered", ptr);
+}
 
 MI_API mi_status mi_ctx_create(int device_id, mi_ctx **out) {
     if (!out) return fail(MI_ERR_INVALID, "mi_ctx_create: out is NULL");
@@ -1002,8 +1025,14 @@ struct PathMem {
 #ifdef MI_WAVE_TIMES
 static unsigned long long *g_wt_buf = nullptr; // diagnostic build only: per-wave time stamps of the k_extend launches (mi_kernels.h)
 #endif
+// What mi_render appends to a frame BEFORE the host waits for it: un-permute kernels and the copies to the caller's
+// host buffers, enqueued on the frame's stream behind the join, so that the frame costs one host wait, not two.
+struct PostWork {
+    virtual hipError_t enqueue(hipStream_t st) = 0;
+    virtual ~PostWork() {}
+};
 static mi_status render_batches(mi_ctx *c, const mi_render_params *p, const ShardGeom &g, const BatchPlan &bp, const PathMem *sets, int n_sets,
-                                void *d_rgba_mean, void *d_rgba8, hipStream_t st, mi_stats *stats, bool timed, bool sync) {
+                                void *d_rgba_mean, void *d_rgba8, hipStream_t st, mi_stats *stats, bool timed, bool sync, PostWork *post = nullptr) {
     const int64_t local = shard_pixels(g);
     const int spp = g.samples * g.samples;
     const int levels = p->depth + 2; // rays per path <= D+2 (CpuTracer.cu:119-131)
@@ -1115,6 +1144,7 @@ static mi_status render_batches(mi_ctx *c, const mi_render_params *p, const Shar
         HIPCHK(hipEventRecord(c->ev_join, c->stream2));
         HIPCHK(hipStreamWaitEvent(st, c->ev_join, 0));
     }
+    if (post) HIPCHK(post->enqueue(st));
     if (!sync) return MI_OK;
     for (int s = 0; s < n_sets; s++) HIPCHK(hipMemcpyAsync(c->h_totals + s * kTotals, sets[s].totals, kTotals * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipEventRecord(c->ev[1], st));
@@ -1185,8 +1215,12 @@ static mi_status render_batches(mi_ctx *c, const mi_render_params *p, const Shar
     return MI_OK;
 }
 
+static mi_status render_device_impl(mi_ctx *c, const mi_render_params *p, void *d_rgba_mean, void *d_rgba8, void *stream_v, mi_stats *stats, PostWork *post);
 MI_API mi_status mi_render_device(mi_ctx *c, const mi_render_params *p, void *d_rgba_mean, void *d_rgba8, void *stream_v,
                                   mi_stats *stats) {
+    return render_device_impl(c, p, d_rgba_mean, d_rgba8, stream_v, stats, nullptr);
+}
+static mi_status render_device_impl(mi_ctx *c, const mi_render_params *p, void *d_rgba_mean, void *d_rgba8, void *stream_v, mi_stats *stats, PostWork *post) {
     if (!c) return fail(MI_ERR_INVALID, "ctx is NULL");
     if (!c->has_scene) return fail(MI_ERR_NO_SCENE, "mi_render: no scene uploaded");
     ShardGeom g;
@@ -1265,7 +1299,7 @@ MI_API mi_status mi_render_device(mi_ctx *c, const mi_render_params *p, void *d_
         m.egrid = n_sets > 1 ? c->n_cu * c->extend_wg_two : extend_grid(c);
         m.egrid0 = c->n_cu * c->extend_wg_primary; m.tgrid = c->n_cu * c->tail_wg_per_cu;
     }
-    return render_batches(c, p, g, bp, sets, n_sets, d_rgba_mean, d_rgba8, st, stats, true, true);
+    return render_batches(c, p, g, bp, sets, n_sets, d_rgba_mean, d_rgba8, st, stats, true, true, post);
 }
 
 // ---- the entry point that allocates nothing (workspace: see `scratch` at the top of this file) ----------
@@ -1342,29 +1376,38 @@ MI_API mi_status mi_render(mi_ctx *c, const mi_render_params *p, float *rgba_mea
     const int64_t local = shard_pixels(g);
     HIPCHK(c->out_mean.ensure(std::max<size_t>((size_t)local * 16, 16)));
     HIPCHK(c->out_rgba8.ensure(std::max<size_t>((size_t)local * 4, 16)));
+    if (g.count == 1) {
+        // The whole frame is ours: un-permute on the device and copy each output out, all enqueued behind the frame's
+        // kernels before the one host wait (GpuTracer.cu:181-188: D2H of w*h float4 + a host setPixel loop).  A buffer
+        // the caller pinned with mi_host_register is written by DMA directly; a pageable one goes through the
+        // runtime's staging.
+        const size_t npx = (size_t)g.width * g.height;
+        if (rgb8_out) HIPCHK(c->out_rgb8.ensure(npx * 3));
+        if (rgba_mean_out) HIPCHK(c->out_mean_frame.ensure(npx * 16));
+        struct Post : PostWork {
+            mi_ctx *c; ShardGeom g; int64_t local; size_t npx; float *mean_out; uint8_t *rgb_out;
+            hipError_t enqueue(hipStream_t st) override {
+                hipError_t e = hipSuccess;
+                const dim3 grid((unsigned)((local + MI_BLOCK - 1) / MI_BLOCK));
+                if (rgb_out) {
+                    hipLaunchKernelGGL(k_assemble, grid, dim3(MI_BLOCK), 0, st, g, c->out_rgba8.as<uchar4>(), (int64_t)local, (int64_t)local, c->out_rgb8.as<uint8_t>());
+                    if ((e = hipGetLastError()) != hipSuccess) return e;
+                    if ((e = hipMemcpyAsync(rgb_out, c->out_rgb8.p, npx * 3, hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
+                }
+                if (mean_out) {
+                    hipLaunchKernelGGL(k_unpermute_mean, grid, dim3(MI_BLOCK), 0, st, g, (int64_t)local, c->out_mean.as<float4>(), c->out_mean_frame.as<float4>());
+                    if ((e = hipGetLastError()) != hipSuccess) return e;
+                    if ((e = hipMemcpyAsync(mean_out, c->out_mean_frame.p, npx * 16, hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
+                }
+                return e;
+            }
+        } post;
+        post.c = c; post.g = g; post.local = local; post.npx = npx; post.mean_out = rgba_mean_out; post.rgb_out = rgb8_out;
+        // stats->ms_total then includes the copies: "first launch -> outputs complete"
+        return render_device_impl(c, p, rgba_mean_out ? c->out_mean.p : nullptr, rgb8_out ? c->out_rgba8.p : nullptr, nullptr, stats, &post);
+    }
     mi_status rs = mi_render_device(c, p, rgba_mean_out ? c->out_mean.p : nullptr, rgb8_out ? c->out_rgba8.p : nullptr, nullptr, stats);
     if (rs != MI_OK) return rs;
-    if (g.count == 1) {
-        // the whole frame is ours: un-permute on the device, then one copy per output
-        hipStream_t st = c->stream;
-        const size_t npx = (size_t)g.width * g.height;
-        if (rgb8_out) {
-            HIPCHK(c->out_rgb8.ensure(npx * 3));
-            hipLaunchKernelGGL(k_assemble, dim3((unsigned)((local + MI_BLOCK - 1) / MI_BLOCK)), dim3(MI_BLOCK), 0, st, g, c->out_rgba8.as<uchar4>(),
-                               (int64_t)local, (int64_t)local, c->out_rgb8.as<uint8_t>());
-            HIPCHK(hipGetLastError());
-            HIPCHK(hipMemcpyAsync(rgb8_out, c->out_rgb8.p, npx * 3, hipMemcpyDeviceToHost, st));
-        }
-        if (rgba_mean_out) {
-            HIPCHK(c->out_mean_frame.ensure(npx * 16));
-            hipLaunchKernelGGL(k_unpermute_mean, dim3((unsigned)((local + MI_BLOCK - 1) / MI_BLOCK)), dim3(MI_BLOCK), 0, st, g, (int64_t)local,
-                               c->out_mean.as<float4>(), c->out_mean_frame.as<float4>());
-            HIPCHK(hipGetLastError());
-            HIPCHK(hipMemcpyAsync(rgba_mean_out, c->out_mean_frame.p, npx * 16, hipMemcpyDeviceToHost, st));
-        }
-        HIPCHK(hipStreamSynchronize(st));
-        return MI_OK;
-    }
     // a shard of the frame: pixels of tiles it does not own must stay untouched in the caller's
     // buffers, so its tiles are scattered on the host
     std::vector<float> mean;

@@ -49,10 +49,12 @@ bool Tracer::loadSceneText(const std::string &text) {
 }
 
 void Tracer::traceSetup(int w, int h) { // tracer.cu:87-93
+    bufferWillChange();
     buffer.resize((size_t)w * h * 3);
     buffer_width = w;
     buffer_height = h;
     std::fill(buffer.begin(), buffer.end(), 0);
+    bufferChanged();
 }
 
 // TraceUI.cu:70-148: the six names are recognised by "pos"/"neg" followed (anywhere later)
@@ -127,8 +129,20 @@ HipTracer::HipTracer(const TraceOptions &o) : Tracer(o), opts_(o) {
     }
 }
 
+// The RGB8 frame buffer is written by every traceImage: pinned while it lives, mi_render's copy is one DMA into it.
+void HipTracer::bufferWillChange() {
+    if (worker_.joinable()) worker_.join();
+    if (pinned_) (void)mi_host_unregister(pinned_);
+    pinned_ = nullptr;
+}
+void HipTracer::bufferChanged() {
+    if ((ctx_ || group_) && !buffer.empty() && mi_host_register(buffer.data(), buffer.size()) == MI_OK) pinned_ = buffer.data();
+    // a refusal only means the slower pageable copy
+}
+
 HipTracer::~HipTracer() {
     if (worker_.joinable()) worker_.join();
+    if (pinned_) (void)mi_host_unregister(pinned_);
     if (ctx_) mi_ctx_destroy(ctx_);
     if (group_) mi_group_destroy(group_);
 }

@@ -47,6 +47,8 @@ public:
     Scene *getScene() { return scene; }
 
 protected:
+    virtual void bufferWillChange() {}            // traceSetup is about to resize `buffer`
+    virtual void bufferChanged() {}               // ... and has done so
     virtual bool sceneLoaded() { return true; }
     virtual bool cubemapLoaded() { return true; }
     struct Face { int w = 0, h = 0; std::vector<unsigned char> rgb; };
@@ -77,6 +79,8 @@ public:
 protected:
     bool sceneLoaded() override;
     bool cubemapLoaded() override;
+    void bufferWillChange() override;             // the frame buffer is pinned while it lives (mi_host_register)
+    void bufferChanged() override;
 
 private:
     TraceOptions opts_;
@@ -86,6 +90,7 @@ private:
     mi_stats stats_{};
     mi_status status_ = MI_OK;
     std::string error_;
+    void *pinned_ = nullptr;
 };
 
 // Image output (counterpart of src/fileio/images.cu:59-68): ".png" -> PNG RGB8,

@@ -93,12 +93,17 @@ class Context:
         return N.RenderParams(width, height, samples, depth, seed, tile[0], tile[1], shard[0], shard[1], batch_paths,
                               1 if count_work else 0, (N.MI_RENDER_ONE_STREAM if one_stream else 0) | (N.MI_RENDER_LAUNCH_TIMES if launch_times else 0))
 
-    def render(self, params, want_mean=True, want_rgb8=True):
+    def render(self, params, want_mean=True, want_rgb8=True, rgb_out=None):
         """Host-buffer render.  Returns (mean float32[h,w,4] | None, rgb8 uint8[h,w,3] | None, Stats);
-        row 0 is the bottom row (src/tracer.cu:96)."""
+        row 0 is the bottom row (src/tracer.cu:96).  rgb_out: a caller-owned uint8[h,w,3] array to render into
+        (e.g. one pinned with host_register, as pt::HipTracer pins its frame buffer)."""
         w, h = params.width, params.height
         mean = np.zeros((h, w, 4), np.float32) if want_mean else None
-        rgb = np.zeros((h, w, 3), np.uint8) if want_rgb8 else None
+        if rgb_out is not None:
+            if rgb_out.dtype != np.uint8 or rgb_out.shape != (h, w, 3) or not rgb_out.flags.c_contiguous:
+                raise ValueError("rgb_out must be a contiguous uint8[h, w, 3] array")
+            want_rgb8 = True
+        rgb = rgb_out if rgb_out is not None else (np.zeros((h, w, 3), np.uint8) if want_rgb8 else None)
         st = N.Stats()
         N.check(N.mi.mi_render(self._h, C.byref(params), mean.ctypes.data if want_mean else None,
                                rgb.ctypes.data if want_rgb8 else None, C.byref(st)))
@@ -202,6 +207,15 @@ class Group:
         st = N.Stats()
         N.check(N.mi.mi_group_render(self._h, C.byref(params), rgb.ctypes.data, C.byref(st)))
         return rgb, st
+
+
+def host_register(array):
+    """mi_host_register: pin a numpy array the caller keeps alive and renders into repeatedly."""
+    N.check(N.mi.mi_host_register(array.ctypes.data, array.nbytes))
+
+
+def host_unregister(array):
+    N.check(N.mi.mi_host_unregister(array.ctypes.data))
 
 
 def shard_pixels(params):
