@@ -354,18 +354,17 @@ def main():
                     rh += ctx.render(pf, want_mean=False, rgb_out=buf)[2].rays_cast
                 return rh / (time.perf_counter() - t1) / 1e6
 
-            # as the Tracer does it: ONE frame buffer (tracer.cu:87-93), pinned while it lives (pt::HipTracer::bufferChanged ->
-            # mi_host_register), every traceImage renders into it
-            fb = np.zeros((h, w, 3), np.uint8)
-            pageable = host_rate(fb)
-            P.host_register(fb)
-            pinned = host_rate(fb)
-            P.host_unregister(fb)
+            # as the Tracer does it: ONE frame buffer (tracer.cu:87-93) that every traceImage renders into; pt::HipTracer keeps it
+            # in pinned host memory (frameAlloc -> mi_host_alloc)
+            pageable = host_rate(np.zeros((h, w, 3), np.uint8))
+            pf_buf = P.PinnedFrame(h, w)
+            pinned = host_rate(pf_buf.array)
+            pf_buf.close()
             out["value_host_output"] = {"value": pinned, "unit": "Mrays/s", "steps": n_h, "frac_of_value": pinned / (rays_all / dt_max / 1e6),
                                         "pageable": pageable,
                                         "what": "mi_render with the RGB8 frame copied to the Tracer's host frame buffer (what HipTracer::traceImage calls), "
-                                                "PCIe-inclusive; `value`: the buffer pinned with mi_host_register, as pt::HipTracer pins it in traceSetup; "
-                                                "`pageable`: the same into an unpinned buffer"}
+                                                "PCIe-inclusive; `value`: the buffer in pinned host memory (mi_host_alloc), where pt::HipTracer keeps it; "
+                                                "`pageable`: the same into an ordinary buffer"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"], band = cpu_baseline(scene, w, h, samples, depth, args.cpu_seconds)
             # SURVEY 8(d) "B2": what a user of the reference's own CpuTracer gets on a mesh of this class — its source cannot

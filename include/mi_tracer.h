@@ -264,15 +264,15 @@ mi_status mi_render_device_noalloc(mi_ctx *ctx, const mi_render_params *params,
  * in the reference. */
 int64_t mi_noalloc_workspace_bytes(void);
 
-/* Pins a host buffer the caller owns and will hand to mi_render / mi_group_render again and again (the Tracer's
- * RGB8 `buffer`, tracer.h:47 / tracer.cu:87-93), so that the frame is written into it by DMA instead of through the
- * runtime's staging copies for pageable memory (C3 at 1080p: the 6.2-MB frame costs ~0.5 ms pageable, ~0.15 ms
- * pinned).  Replaces nothing in the reference (GpuTracer.cu:181 copies w*h float4 to pageable memory and converts on
- * the host, :186-188).  Process-wide, any device; the buffer must stay allocated until mi_host_unregister(ptr) —
- * unregister BEFORE freeing or resizing it.  Registering the same (ptr, bytes) twice is a no-op; MI_ERR_HIP if the
- * runtime refuses (e.g. memory that is already pinned). */
-mi_status mi_host_register(void *ptr, size_t bytes);
-mi_status mi_host_unregister(void *ptr);
+/* Pinned (page-locked, DMA-able) host memory for the buffers the caller hands to mi_render / mi_group_render again
+ * and again — the Tracer's RGB8 frame `buffer` (tracer.h:47, tracer.cu:87-93).  A frame rendered into such a buffer
+ * arrives by one DMA behind the last kernel; into ordinary pageable memory it goes through the runtime's staging
+ * copies (C3 at 1080p, 6.2 MB: DESIGN.md section 6 has both rates).  Replaces nothing in the reference
+ * (GpuTracer.cu:181 copies w*h float4 to pageable memory and converts on the host, :186-188).  The memory is plain
+ * host memory to the CPU; release it with mi_host_free (NULL is ignored) after the last render into it has
+ * returned.  MI_ERR_OOM / MI_ERR_HIP if the runtime cannot provide it: fall back to an ordinary buffer. */
+mi_status mi_host_alloc(size_t bytes, void **out);
+void mi_host_free(void *ptr);
 
 /* Number of local pixel slots (owned tiles * tile_w * tile_h) of a shard. */
 int64_t mi_shard_pixels(const mi_render_params *params);

@@ -5,4 +5,4 @@ Python here is only a binding layer over the two native libraries built by ``mak
 BVH build, the Tracer interface).  Importing fails if they are not built."""
 from ._native import MiError, RenderParams, SceneSoA, Stats  # noqa: F401
 from .scene import Scene  # noqa: F401
-from .tracer import Context, Group, HipTracer, host_register, host_unregister, match_cubemap_files, read_image, shard_pixels  # noqa: F401
+from .tracer import Context, Group, HipTracer, PinnedFrame, match_cubemap_files, read_image, shard_pixels  # noqa: F401

@@ -76,7 +76,7 @@ MI_SYMBOLS = [
     "mi_ctx_create", "mi_ctx_destroy", "mi_scene_upload", "mi_scene_upload_build", "mi_scene_quality",
     "mi_scene_download_nodes", "mi_scene_download_nodes4", "mi_scene_download_prim_ids", "mi_cubemap_upload", "mi_render", "mi_render_device", "mi_shard_pixels",
     "mi_assemble_rgb8", "mi_assemble_rgb8_device", "mi_trace_primary", "mi_trace_rays", "mi_occluded_rays", "mi_last_error", "mi_abi_version",
-    "mi_render_device_noalloc", "mi_noalloc_workspace_bytes", "mi_host_register", "mi_host_unregister",
+    "mi_render_device_noalloc", "mi_noalloc_workspace_bytes", "mi_host_alloc", "mi_host_free",
     "mi_group_create", "mi_group_destroy", "mi_group_size", "mi_group_scene_upload", "mi_group_scene_upload_build",
     "mi_group_cubemap_upload", "mi_group_render",
 ]
@@ -105,10 +105,10 @@ mi.mi_render_device.restype = C.c_int
 mi.mi_render_device_noalloc.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Stats)]
 mi.mi_render_device_noalloc.restype = C.c_int
 mi.mi_noalloc_workspace_bytes.restype = C.c_int64
-mi.mi_host_register.argtypes = [C.c_void_p, C.c_size_t]
-mi.mi_host_register.restype = C.c_int
-mi.mi_host_unregister.argtypes = [C.c_void_p]
-mi.mi_host_unregister.restype = C.c_int
+mi.mi_host_alloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
+mi.mi_host_alloc.restype = C.c_int
+mi.mi_host_free.argtypes = [C.c_void_p]
+mi.mi_host_free.restype = None
 mi.mi_shard_pixels.argtypes = [C.POINTER(RenderParams)]
 mi.mi_shard_pixels.restype = C.c_int64
 mi.mi_assemble_rgb8.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.c_void_p, C.c_int64, C.c_void_p]

@@ -183,27 +183,18 @@ static size_t stack_bytes(const mi_ctx *c) { return (size_t)(MI_MAX_STACK - MI_L
 MI_API int mi_abi_version(void) { return 13; }
 MI_API const char *mi_last_error(void) { return g_err.c_str(); }
 
-// Pinned caller buffers (process-wide; hipHostRegisterPortable: every device's DMA engines may write them).
-static std::mutex g_pin_mutex;
-static std::vector<std::pair<void *, size_t>> g_pinned;
-MI_API mi_status mi_host_register(void *ptr, size_t bytes) {
-    if (!ptr || bytes == 0) return fail(MI_ERR_INVALID, "mi_host_register: empty buffer");
-    std::lock_guard<std::mutex> lock(g_pin_mutex);
-    for (auto &q : g_pinned)
-        if (q.first == ptr) return q.second == bytes ? MI_OK : fail(MI_ERR_INVALID, "mi_host_register: %p is registered with another size", ptr);
-    HIPCHK(hipHostRegister(ptr, bytes, hipHostRegisterPortable));
-    g_pinned.push_back({ptr, bytes});
+// Pinned host memory for the caller's frame buffer (hipHostMalloc: DMA-able from every device).  The library
+// hands it out instead of pinning the caller's own pages: hipHostRegister is refused on some deployments
+// (containers without user-pointer pinning; the MI355X pool this was developed on is one).
+MI_API mi_status mi_host_alloc(size_t bytes, void **out) {
+    if (!out) return fail(MI_ERR_INVALID, "mi_host_alloc: out is NULL");
+    *out = nullptr;
+    if (bytes == 0) return fail(MI_ERR_INVALID, "mi_host_alloc: zero bytes");
+    HIPCHK(hipHostMalloc(out, bytes, hipHostMallocPortable));
     return MI_OK;
 }
-MI_API mi_status mi_host_unregister(void *ptr) {
-    std::lock_guard<std::mutex> lock(g_pin_mutex);
-    for (size_t i = 0; i < g_pinned.size(); i++)
-        if (g_pinned[i].first == ptr) {
-            g_pinned.erase(g_pinned.begin() + (long)i);
-            HIPCHK(hipHostUnregister(ptr));
-            return MI_OK;
-        }
-    return fail(MI_ERR_INVALID, "mi_host_unregister: %p was not registered", ptr);
+MI_API void mi_host_free(void *ptr) {
+    if (ptr) (void)hipHostFree(ptr);
 }
 
 MI_API mi_status mi_ctx_create(int device_id, mi_ctx **out) {

@@ -10,7 +10,16 @@
 
 namespace pt {
 
-Tracer::~Tracer() { delete scene; }
+Tracer::~Tracer() {
+    releaseFrame();
+    delete scene;
+}
+
+void Tracer::releaseFrame() {
+    if (buffer.p) frameFree(buffer.p);
+    buffer.p = nullptr;
+    buffer.n = 0;
+}
 
 void Tracer::getBuffer(unsigned char *&buf, int &w, int &h) { // tracer.cu:32-36
     buf = buffer.data();
@@ -49,12 +58,15 @@ bool Tracer::loadSceneText(const std::string &text) {
 }
 
 void Tracer::traceSetup(int w, int h) { // tracer.cu:87-93
-    bufferWillChange();
-    buffer.resize((size_t)w * h * 3);
+    waitRender();                                 // a render in flight still writes the old frame
+    const size_t bytes = (size_t)w * h * 3;
+    if (bytes != buffer.n) {
+        releaseFrame();
+        if (bytes) { buffer.p = frameAlloc(bytes); buffer.n = bytes; }
+    }
     buffer_width = w;
     buffer_height = h;
-    std::fill(buffer.begin(), buffer.end(), 0);
-    bufferChanged();
+    if (bytes) std::memset(buffer.p, 0, bytes);
 }
 
 // TraceUI.cu:70-148: the six names are recognised by "pos"/"neg" followed (anywhere later)
@@ -129,20 +141,20 @@ HipTracer::HipTracer(const TraceOptions &o) : Tracer(o), opts_(o) {
     }
 }
 
-// The RGB8 frame buffer is written by every traceImage: pinned while it lives, mi_render's copy is one DMA into it.
-void HipTracer::bufferWillChange() {
-    if (worker_.joinable()) worker_.join();
-    if (pinned_) (void)mi_host_unregister(pinned_);
-    pinned_ = nullptr;
+// The RGB8 frame is written by every traceImage: in pinned memory, mi_render's copy is one DMA into it.
+unsigned char *HipTracer::frameAlloc(size_t bytes) {
+    void *p = nullptr;
+    if ((ctx_ || group_) && mi_host_alloc(bytes, &p) == MI_OK && p) { pinned_ = (unsigned char *)p; return pinned_; }
+    return Tracer::frameAlloc(bytes);             // a refusal only means the slower pageable copy
 }
-void HipTracer::bufferChanged() {
-    if ((ctx_ || group_) && !buffer.empty() && mi_host_register(buffer.data(), buffer.size()) == MI_OK) pinned_ = buffer.data();
-    // a refusal only means the slower pageable copy
+void HipTracer::frameFree(unsigned char *p) {
+    if (p && p == pinned_) { mi_host_free(p); pinned_ = nullptr; }
+    else Tracer::frameFree(p);
 }
 
 HipTracer::~HipTracer() {
     if (worker_.joinable()) worker_.join();
-    if (pinned_) (void)mi_host_unregister(pinned_);
+    releaseFrame();                               // while frameFree still dispatches here and the runtime is up
     if (ctx_) mi_ctx_destroy(ctx_);
     if (group_) mi_group_destroy(group_);
 }

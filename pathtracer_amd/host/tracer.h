@@ -47,8 +47,11 @@ public:
     Scene *getScene() { return scene; }
 
 protected:
-    virtual void bufferWillChange() {}            // traceSetup is about to resize `buffer`
-    virtual void bufferChanged() {}               // ... and has done so
+    // Storage of the RGB8 frame (the reference's `std::vector<uchar> buffer`, tracer.h:47): a backend may supply
+    // memory of its own kind — HipTracer hands out pinned host memory (mi_host_alloc) so that a frame arrives by DMA.
+    virtual unsigned char *frameAlloc(size_t bytes) { return new unsigned char[bytes]; }
+    virtual void frameFree(unsigned char *p) { delete[] p; }
+    void releaseFrame();                          // derived destructors call it while their frameFree is still reachable
     virtual bool sceneLoaded() { return true; }
     virtual bool cubemapLoaded() { return true; }
     struct Face { int w = 0, h = 0; std::vector<unsigned char> rgb; };
@@ -57,7 +60,13 @@ protected:
     unsigned depth;
     unsigned samples;
     Scene *scene = nullptr;
-    std::vector<unsigned char> buffer;            // RGB8, row 0 = bottom row
+    struct Frame {                                // RGB8, row 0 = bottom row
+        unsigned char *p = nullptr;
+        size_t n = 0;
+        unsigned char *data() const { return p; }
+        size_t size() const { return n; }
+        bool empty() const { return n == 0; }
+    } buffer;
     int buffer_width = 0, buffer_height = 0;
 };
 
@@ -79,8 +88,8 @@ public:
 protected:
     bool sceneLoaded() override;
     bool cubemapLoaded() override;
-    void bufferWillChange() override;             // the frame buffer is pinned while it lives (mi_host_register)
-    void bufferChanged() override;
+    unsigned char *frameAlloc(size_t bytes) override;   // pinned host memory; ordinary memory if the runtime has none
+    void frameFree(unsigned char *p) override;
 
 private:
     TraceOptions opts_;
@@ -90,7 +99,7 @@ private:
     mi_stats stats_{};
     mi_status status_ = MI_OK;
     std::string error_;
-    void *pinned_ = nullptr;
+    unsigned char *pinned_ = nullptr;             // the frame, when it came from mi_host_alloc
 };
 
 // Image output (counterpart of src/fileio/images.cu:59-68): ".png" -> PNG RGB8,

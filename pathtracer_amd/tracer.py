@@ -209,13 +209,23 @@ class Group:
         return rgb, st
 
 
-def host_register(array):
-    """mi_host_register: pin a numpy array the caller keeps alive and renders into repeatedly."""
-    N.check(N.mi.mi_host_register(array.ctypes.data, array.nbytes))
+class PinnedFrame:
+    """uint8[h, w, 3] frame buffer in pinned host memory (mi_host_alloc), as pt::HipTracer keeps its `buffer`:
+    ``.array`` is a numpy view; ``close()`` releases the memory (the view must not be used afterwards)."""
 
+    def __init__(self, h, w):
+        p = C.c_void_p()
+        N.check(N.mi.mi_host_alloc(h * w * 3, C.byref(p)))
+        self._p = p
+        self.array = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_ubyte)), shape=(h, w, 3))
 
-def host_unregister(array):
-    N.check(N.mi.mi_host_unregister(array.ctypes.data))
+    def close(self):
+        p, self._p = getattr(self, "_p", None), None
+        self.array = None
+        if p and N is not None and getattr(N, "mi", None) is not None:
+            N.mi.mi_host_free(p)
+
+    __del__ = close
 
 
 def shard_pixels(params):
