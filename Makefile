@@ -8,7 +8,11 @@ CXX ?= g++
 ARCH ?= gfx950
 # -ffp-contract=off: the numerics contract — no FMA contraction, so
 # device results match the oracle bit for bit.
-HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function
+HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function $(EXTRA_HIPFLAGS)
+# make WIDE8=1: the 8-wide node format (mi_trav8.h, mi_wide8.h) instead of the quantised 4-wide one
+ifeq ($(WIDE8),1)
+HIPFLAGS += -DMI_WIDE8
+endif
 CXXFLAGS = -O2 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -pthread
 LIB = pathtracer_amd/lib
 BIN = pathtracer_amd/bin
@@ -18,7 +22,7 @@ HOST_HDR = pathtracer_amd/host/scene.h pathtracer_amd/host/tracer.h pathtracer_a
 
 all: $(LIB)/libmi_tracer.so $(LIB)/libpt_host.so $(BIN)/ray oracle/liboracle.so
 
-$(LIB)/libmi_tracer.so: pathtracer_amd/csrc/mi_tracer.hip pathtracer_amd/csrc/mi_kernels.h pathtracer_amd/csrc/mi_bvh_build.h include/mi_tracer.h
+$(LIB)/libmi_tracer.so: pathtracer_amd/csrc/mi_tracer.hip pathtracer_amd/csrc/mi_kernels.h pathtracer_amd/csrc/mi_bvh_build.h pathtracer_amd/csrc/mi_trav8.h pathtracer_amd/csrc/mi_wide8.h include/mi_tracer.h
 	@mkdir -p $(LIB)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ pathtracer_amd/csrc/mi_tracer.hip
 
@@ -32,7 +36,16 @@ $(BIN)/ray: pathtracer_amd/host/ray_main.cpp $(LIB)/libpt_host.so
 oracle/liboracle.so: oracle/oracle.cpp include/mi_tracer.h
 	$(MAKE) -C oracle
 
-clean:
-	rm -rf $(LIB) $(BIN) oracle/liboracle.so
+# The same libraries with the 8-wide node format, beside the default build: MI_TRACER_LIB_DIR=pathtracer_amd/lib8 selects them
+LIB8 = pathtracer_amd/lib8
+wide8: $(LIB8)/libmi_tracer.so $(LIB8)/libpt_host.so
+$(LIB8)/libmi_tracer.so: pathtracer_amd/csrc/mi_tracer.hip pathtracer_amd/csrc/mi_kernels.h pathtracer_amd/csrc/mi_bvh_build.h pathtracer_amd/csrc/mi_trav8.h pathtracer_amd/csrc/mi_wide8.h include/mi_tracer.h
+	@mkdir -p $(LIB8)
+	$(HIPCC) $(HIPFLAGS) -DMI_WIDE8 -shared -o $@ pathtracer_amd/csrc/mi_tracer.hip
+$(LIB8)/libpt_host.so: $(HOST_SRC) $(HOST_HDR) $(LIB8)/libmi_tracer.so
+	$(CXX) $(CXXFLAGS) -shared -o $@ $(HOST_SRC) -L$(LIB8) -lmi_tracer -lz -Wl,-rpath,'$$ORIGIN'
 
-.PHONY: all clean
+clean:
+	rm -rf $(LIB) $(LIB8) $(BIN) oracle/liboracle.so
+
+.PHONY: all clean wide8

@@ -11,7 +11,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_DIR = os.path.join(_HERE, "lib")
+# MI_TRACER_LIB_DIR: another build of the two libraries (e.g. lib8/: `make wide8`, the 8-wide node format) — never a fallback
+LIB_DIR = os.environ.get("MI_TRACER_LIB_DIR") or os.path.join(_HERE, "lib")
 
 
 class MiError(RuntimeError):

@@ -23,9 +23,12 @@
 #include <stdint.h>
 
 #define MI_BLOCK 256          // threads per workgroup = 4 waves of 64
-#define MI_LDS_STACK 12       // traversal stack entries per lane held in LDS
 #define MI_MAX_DEPTH 64       // deepest (binary) tree the uploader accepts
+#ifndef MI_WIDE8
+#define MI_LDS_STACK 12       // traversal stack entries per lane held in LDS
 #define MI_MAX_STACK 192      // up to three pushes per level of the 4-wide tree collapsed from it
+#define MI_STACK_ELEM_BYTES 4
+#endif
 #define MI_NO_HIT 12345678.9f // ray.h:14
 #define MI_EPS 0.00001f       // ray.h:12
 
@@ -59,7 +62,7 @@ struct DevScene {
     // first from the root, at most MI_TREELET nodes) that every workgroup keeps in LDS.
     int32_t treelet_base, treelet_count;
 };
-#ifndef MI_TREELET
+#if !defined(MI_TREELET) && !defined(MI_WIDE8)
 #define MI_TREELET 69        // nodes (4.4 KB; 138 measured no better): with the 12-KB stack, seven workgroups of k_extend fit the CU's 160 KB of LDS
 #endif
 #define MI_Q_PAD 0           // whole codes a quantised plane is moved outward beyond its rounding
@@ -451,6 +454,9 @@ __device__ __forceinline__ bool tail_took_over(const uint32_t *tail_level, int l
 
 #define MI_DONE 0x7fffffff
 #define MI_NONE 0x7ffffffe // "pop next": no valid ref (node indices and leaf refs are below 2^26 in magnitude)
+#ifdef MI_WIDE8
+#include "mi_trav8.h"
+#else
 // Per-lane traversal state of the persistent kernels.
 struct Lane {
     f3 o, d;
@@ -459,6 +465,20 @@ struct Lane {
     Hit h;
     int cur, sp; // cur: >= 0 node to visit, < 0 leaf ~cur to test, MI_DONE finished
 };
+typedef int mi_stack_elem;
+typedef int mi_ovf_elem;
+#define MI_TREELET_U4 (MI_TREELET * 4)
+__device__ __forceinline__ void lane_idle(Lane &L) {
+    L.cur = MI_DONE; L.sp = 0;
+    L.h = Hit{MI_NO_HIT, -1};
+    L.o = L.d = mk3(0, 0, 0);
+    L.ax = L.ay = L.az = make_float2(0.0f, 0.0f);
+    L.seln[0] = L.seln[1] = L.seln[2] = MI_Q_SEL_LO;
+}
+__device__ __forceinline__ bool lane_wants_leaf(const Lane &L) { return L.cur < 0; }
+__device__ __forceinline__ bool lane_wants_node(const Lane &L) { return L.cur >= 0 && L.cur != MI_DONE; }
+__device__ __forceinline__ bool lane_done(const Lane &L) { return L.cur == MI_DONE; }
+__device__ __forceinline__ void lane_finish(Lane &L) { L.cur = MI_DONE; L.sp = 0; } // any-hit: the query is answered
 __device__ __forceinline__ void lane_start(const DevScene &sc, Lane &L, f3 o, f3 d, float t0 = MI_NO_HIT) {
     L.o = o;
     L.d = d;
@@ -482,6 +502,7 @@ __device__ __forceinline__ void lane_start(const DevScene &sc, Lane &L, f3 o, f3
     L.cur = sc.n_tri + sc.n_sph == 0 ? MI_DONE : sc.root_ref;
 }
 typedef __attribute__((address_space(3))) int lds_int; // LDS-qualified, so stack accesses can only be ds_read/ds_write
+typedef lds_int mi_lds_stack;
 // Pop the next node / leaf (MI_DONE when the stack is empty).  The LDS read is
 // unconditional (clamped index) and the rare overflow entry overrides it: a `?:` over the
 // two address spaces compiles to one flat_load, which is slower than ds_read and makes
@@ -519,6 +540,10 @@ __device__ __forceinline__ void cswap(bool sw, float &ka, float &kb, int &ra, in
 struct NodeBase {
     uint64_t base, delta;
 };
+// every thread of the workgroup; the caller synchronises
+__device__ __forceinline__ void treelet_load(const DevScene &sc, uint4 *lds) {
+    for (int i = threadIdx.x; i < sc.treelet_count * 4; i += MI_BLOCK) lds[i] = sc.qnodes[(size_t)sc.treelet_base * 4 + i];
+}
 __device__ __forceinline__ NodeBase node_base(const DevScene &sc, const uint4 *treelet) {
     const uint64_t g = (uint64_t)(uintptr_t)sc.qnodes;
     const uint64_t l = (uint64_t)(uintptr_t)treelet; // generic (flat) address of the LDS array
@@ -612,7 +637,7 @@ __device__ __forceinline__ void merged_step(const DevScene &sc, Lane &L, lds_int
         if (is_sph) sphere_test_rec(sc, slot, f4(r0), L.o, L.d, L.h);
         else tri_test_rec(sc, slot, f4(r0), f4(r1), f4(r2), L.o, L.d, L.h);
         L.cur = MI_NONE;
-        if (ANY && L.h.slot >= 0) { L.cur = MI_DONE; L.sp = 0; }
+        if (ANY && L.h.slot >= 0) lane_finish(L);
     } else {
         node_process<false>(sc, L, stack, my_ovf, ovf_stride, r0, r1, r2, make_int4((int)r3.x, (int)r3.y, (int)r3.z, (int)r3.w));
     }
@@ -622,6 +647,8 @@ __device__ __forceinline__ void leaf_phase(const DevScene &sc, Lane &L, lds_int 
     prim_test(sc, ~L.cur, L.o, L.d, L.h);
     lane_pop(L, stack, my_ovf, ovf_stride);
 }
+
+#endif // MI_WIDE8
 
 // Persistent waves, per-lane ray refill, and leaf tests postponed to their own phase.
 //
@@ -658,17 +685,17 @@ k_extend(DevScene sc, const uint32_t *count_ptr, uint32_t fixed_count, uint32_t 
          const float4 *ray_o, const float4 *ray_d, float2 *hits, int *ovf, unsigned long long *work_stats, int refill_min,
          int leaf_min, ShardGeom g, uint32_t pix0, uint32_t npix, FastDiv d_npix, uint32_t *primary_count,
          const uint32_t *tail_level, int level, uint32_t deal_rot) {
-    __shared__ int lds_stack[MI_LDS_STACK * MI_BLOCK];
+    __shared__ mi_stack_elem lds_stack[MI_LDS_STACK * MI_BLOCK];
     if (!PRIMARY && tail_level && tail_took_over(tail_level, level)) return;
-    __shared__ uint4 lds_treelet[MI_TREELET * 4];
-    for (int i = threadIdx.x; i < sc.treelet_count * 4; i += MI_BLOCK) lds_treelet[i] = sc.qnodes[(size_t)sc.treelet_base * 4 + i];
+    __shared__ uint4 lds_treelet[MI_TREELET_U4];
+    treelet_load(sc, lds_treelet);
     __syncthreads();
     const NodeBase nbase = node_base(sc, lds_treelet);
 
     const int lane = threadIdx.x & 63;
-    lds_int *stack = (lds_int *)lds_stack + threadIdx.x;
+    mi_lds_stack *stack = (mi_lds_stack *)lds_stack + threadIdx.x;
     const size_t ovf_stride = (size_t)gridDim.x * MI_BLOCK;
-    int *my_ovf = ovf + (size_t)blockIdx.x * MI_BLOCK + threadIdx.x;
+    mi_ovf_elem *my_ovf = (mi_ovf_elem *)ovf + (size_t)blockIdx.x * MI_BLOCK + threadIdx.x;
     // Work distribution in 64-ray chunks, dealt statically and interleaved over the waves
     // (wave w takes virtual chunks w, w+W, w+2W, ...): no atomics (a work cursor on one
     // word cost 6 of 7 ms at level 0), and every wave sees the same mix of image regions.
@@ -693,11 +720,7 @@ k_extend(DevScene sc, const uint32_t *count_ptr, uint32_t fixed_count, uint32_t 
     bool active = false;
     uint32_t slot = 0;
     Lane L;
-    L.cur = MI_DONE; L.sp = 0;
-    L.h = Hit{MI_NO_HIT, -1};
-    L.o = L.d = mk3(0, 0, 0);
-    L.ax = L.ay = L.az = make_float2(0.0f, 0.0f);
-    L.seln[0] = L.seln[1] = L.seln[2] = MI_Q_SEL_LO;
+    lane_idle(L);
     unsigned long long act = 0ull; // ballot of `active`
     // Level 0: the camera rays of a chunk are computed by all 64 lanes at once when the wave
     // takes the chunk, and parked in LDS until the refills hand them out.  (Computed inside
@@ -769,8 +792,8 @@ k_extend(DevScene sc, const uint32_t *count_ptr, uint32_t fixed_count, uint32_t 
 #ifdef MI_WAVE_TIMES
         wt_iters++;
 #endif
-        const bool want_leaf = active && L.cur < 0;
-        const bool want_node = active && L.cur >= 0 && L.cur != MI_DONE;
+        const bool want_leaf = active && lane_wants_leaf(L);
+        const bool want_node = active && lane_wants_node(L);
         const int nl = __popcll(__ballot(want_leaf)), nn = __popcll(__ballot(want_node));
         if (COUNT && lane == 0) { // lane slots of this iteration by state (instrumented variant only)
             const bool leaf_it = !more ? false : (nl > 0 && (nl >= leaf_min || nn == 0));
@@ -788,7 +811,7 @@ k_extend(DevScene sc, const uint32_t *count_ptr, uint32_t fixed_count, uint32_t 
             if (want_leaf) {
                 if (COUNT) n_leaves++;
                 leaf_phase(sc, L, stack, my_ovf, ovf_stride);
-                if (ANY && L.h.slot >= 0) { L.cur = MI_DONE; L.sp = 0; } // first accepted hit ends the query
+                if (ANY && L.h.slot >= 0) lane_finish(L); // first accepted hit ends the query
             }
         } else if (want_node) {
             if (COUNT) {
@@ -797,7 +820,7 @@ k_extend(DevScene sc, const uint32_t *count_ptr, uint32_t fixed_count, uint32_t 
             }
             node_phase(sc, L, stack, my_ovf, ovf_stride, nbase);
         }
-        if (active && L.cur == MI_DONE) {
+        if (active && lane_done(L)) {
             hits[slot] = make_float2(L.h.t, __int_as_float(L.h.slot));
             active = false;
             if (COUNT) { max_ray_steps = max(max_ray_steps, ray_steps); ray_steps = 0; }
@@ -1148,22 +1171,22 @@ __global__ void __launch_bounds__(MI_BLOCK, 5)
 k_tail(DevScene sc, ShardGeom g, uint32_t pix0, uint32_t npix, FastDiv d_npix, int level0, int depth_total, uint64_t seed, RayStream in,
        const uint32_t *count_ptr, uint32_t threshold, uint32_t *tail_level, float4 *hist, size_t cap, size_t e_off, float4 *path_out, int *ovf,
        unsigned long long *extra_rays, int shade_min, int refill_min) {
-    __shared__ int lds_stack[MI_LDS_STACK * MI_BLOCK];
+    __shared__ mi_stack_elem lds_stack[MI_LDS_STACK * MI_BLOCK];
     const uint32_t n = stream_total(count_ptr);
     const uint32_t tl = *tail_level;
     // same decision in every wave: tl is only ever written with level0 by this launch
     if (n == 0 || n > threshold || (tl != 0 && tl != (uint32_t)level0)) return;
-    __shared__ uint4 lds_treelet[MI_TREELET * 4];
-    for (int i = threadIdx.x; i < sc.treelet_count * 4; i += MI_BLOCK) lds_treelet[i] = sc.qnodes[(size_t)sc.treelet_base * 4 + i];
+    __shared__ uint4 lds_treelet[MI_TREELET_U4];
+    treelet_load(sc, lds_treelet);
     __syncthreads();
     const NodeBase nbase = node_base(sc, lds_treelet);
     __shared__ float4 lds_mats[5 * MI_LDS_MATS];
     const MatTable mt = mat_table_load(sc, lds_mats);
     const int lane = threadIdx.x & 63;
     if (blockIdx.x == 0 && threadIdx.x == 0) *tail_level = (uint32_t)level0;
-    lds_int *stack = (lds_int *)lds_stack + threadIdx.x;
+    mi_lds_stack *stack = (mi_lds_stack *)lds_stack + threadIdx.x;
     const size_t ovf_stride = (size_t)gridDim.x * MI_BLOCK;
-    int *my_ovf = ovf + (size_t)blockIdx.x * MI_BLOCK + threadIdx.x;
+    mi_ovf_elem *my_ovf = (mi_ovf_elem *)ovf + (size_t)blockIdx.x * MI_BLOCK + threadIdx.x;
     const uint32_t n_waves = gridDim.x * (MI_BLOCK / 64);
     const uint32_t wave_id = __builtin_amdgcn_readfirstlane(blockIdx.x * (MI_BLOCK / 64) + (threadIdx.x >> 6));
     const uint32_t n_chunks = stream_chunks(count_ptr, 0u);
@@ -1177,11 +1200,7 @@ k_tail(DevScene sc, ShardGeom g, uint32_t pix0, uint32_t npix, FastDiv d_npix, i
     int level = level0;
     float4 T = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     Lane L;
-    L.cur = MI_DONE; L.sp = 0;
-    L.h = Hit{MI_NO_HIT, -1};
-    L.o = L.d = mk3(0, 0, 0);
-    L.ax = L.ay = L.az = make_float2(0.0f, 0.0f);
-    L.seln[0] = L.seln[1] = L.seln[2] = MI_Q_SEL_LO;
+    lane_idle(L);
     unsigned long long act = 0ull;
     bool more = true; // wave-uniform
     do {              // single back edge, no `continue` (see k_extend)
@@ -1211,9 +1230,9 @@ k_tail(DevScene sc, ShardGeom g, uint32_t pix0, uint32_t npix, FastDiv d_npix, i
             }
             more = rng_next < rng_end || chunk < n_chunks;
         }
-        const bool want_leaf = active && L.cur < 0;
-        const bool want_node = active && L.cur >= 0 && L.cur != MI_DONE;
-        const bool want_shade = active && L.cur == MI_DONE;
+        const bool want_leaf = active && lane_wants_leaf(L);
+        const bool want_node = active && lane_wants_node(L);
+        const bool want_shade = active && lane_done(L);
         const int nl = __popcll(__ballot(want_leaf)), nn = __popcll(__ballot(want_node)), ns = __popcll(__ballot(want_shade));
         if (ns > 0 && (ns >= shade_min || (nl == 0 && nn == 0))) {
             bool cont = false;

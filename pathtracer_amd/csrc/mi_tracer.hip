@@ -3,6 +3,9 @@
 // with a thread-local message (the reference checks nothing, GpuTracer.cu:161-189).
 #include "mi_kernels.h"
 #include "mi_bvh_build.h"
+#ifdef MI_WIDE8
+#include "mi_wide8.h"
+#endif
 
 #include <algorithm>
 #include <cstdarg>
@@ -133,6 +136,8 @@ struct mi_ctx {
     bool has_scene = false;
     DevScene sc{};
     uint32_t n_nodes = 0;   // of the binary tree kept in `nodes` (download, quality); the kernels walk `nodes4`
+    uint32_t n_nodes8 = 0;  // -DMI_WIDE8: nodes of the 8-wide tree in `qnodes`, and its levels
+    int levels8 = 0;
     int32_t root_ref2 = ~0;
     DevBuf nodes, nodes4, qnodes, tri, tri_normal, tri_mat, tri_has_vmat, tri_shade, sph, sph_mat, mats, prim_id, cube;
     // per-batch path state (sized by slot capacity / depth): two ray streams (level k reads
@@ -173,12 +178,16 @@ static const int kCounterWords = (kMaxLevels + 1) * kLevelWords + MI_CNT_STRIDE;
 
 // Stack entries a ray can need in a tree of `depth2` levels of binary interior nodes: the 4-wide tree has
 // ceil(depth2 / 2) levels and a node visit pushes at most three refs (+ 3 of margin).
+#ifdef MI_WIDE8
+static int stack_need(int depth2) { return std::min(MI_MAX_STACK, (depth2 + 2) / 3 + 2); } // one group entry per level of the 8-wide tree
+#else
 static int stack_need(int depth2) { return std::min(MI_MAX_STACK, 3 * ((depth2 + 1) / 2) + 3); }
+#endif
 static int extend_grid(const mi_ctx *c) { return c->n_cu * c->extend_wg_per_cu; }
 // Workgroups of the largest persistent launch (k_extend, its level-0 variant, k_tail): every one of their
 // threads owns a column of the global overflow stack, indexed by blockIdx.x * MI_BLOCK + threadIdx.x.
 static int stack_grid(const mi_ctx *c) { return c->n_cu * std::max(c->extend_wg_per_cu, std::max(c->extend_wg_primary, c->tail_wg_per_cu)); }
-static size_t stack_bytes(const mi_ctx *c) { return (size_t)(MI_MAX_STACK - MI_LDS_STACK) * stack_grid(c) * MI_BLOCK * 4; }
+static size_t stack_bytes(const mi_ctx *c) { return (size_t)(MI_MAX_STACK - MI_LDS_STACK) * stack_grid(c) * MI_BLOCK * MI_STACK_ELEM_BYTES; }
 
 MI_API int mi_abi_version(void) { return 13; }
 MI_API const char *mi_last_error(void) { return g_err.c_str(); }
@@ -572,6 +581,75 @@ static mi_status install_bvh4(mi_ctx *c, const float *nodes2, int32_t root2) {
     return quantize_nodes4(c, (uint32_t)(n4.size() / 32));
 }
 
+#ifdef MI_WIDE8
+// 8-wide build of the library: the binary tree (host copy) -> 8-wide nodes (mi_wide8.h), the primitive arrays on the
+// device gathered into the order its leaf seats name, nodes uploaded.  Stands where install_bvh4 stands.
+static mi_status install_bvh8(mi_ctx *c, const float *nodes2, int32_t root2) {
+    Wide8Tree t;
+    build_wide8(nodes2, root2, c->sc.n_tri, c->sc.n_sph, t);
+    const uint32_t nt = c->sc.n_tri, ns = c->sc.n_sph, n = nt + ns;
+    hipStream_t st = c->stream;
+    if (root2 >= 0 && n > 1) {
+        if (t.tri_src.size() != nt || t.sph_src.size() != ns) return fail(MI_ERR_INVALID, "internal: 8-wide collapse lost primitives (%zu + %zu of %u + %u)", t.tri_src.size(), t.sph_src.size(), nt, ns);
+        DevBuf d_ts, d_ss, r_tri, r_nrm, r_mat, r_vm, r_sph, r_smat, r_id;
+        DevBuf *tmp[] = {&d_ts, &d_ss, &r_tri, &r_nrm, &r_mat, &r_vm, &r_sph, &r_smat, &r_id};
+        auto body = [&]() -> mi_status {
+            HIPCHK(d_ts.ensure(std::max<size_t>((size_t)nt * 4, 16)));
+            HIPCHK(d_ss.ensure(std::max<size_t>((size_t)ns * 4, 16)));
+            if (nt) HIPCHK(hipMemcpyAsync(d_ts.p, t.tri_src.data(), (size_t)nt * 4, hipMemcpyHostToDevice, st));
+            if (ns) HIPCHK(hipMemcpyAsync(d_ss.p, t.sph_src.data(), (size_t)ns * 4, hipMemcpyHostToDevice, st));
+            HIPCHK(r_tri.ensure((size_t)nt * 48 + 16));
+            HIPCHK(r_nrm.ensure(std::max<size_t>((size_t)nt * 16, 16)));
+            HIPCHK(r_mat.ensure(std::max<size_t>((size_t)nt * 12, 16)));
+            HIPCHK(r_vm.ensure(std::max<size_t>((size_t)nt, 16)));
+            HIPCHK(r_sph.ensure((size_t)ns * 16 + 64));
+            HIPCHK(r_smat.ensure(std::max<size_t>((size_t)ns * 4, 16)));
+            HIPCHK(r_id.ensure((size_t)n * 4));
+            HIPCHK(hipMemsetAsync(r_tri.p, 0, (size_t)nt * 48 + 16, st));
+            HIPCHK(hipMemsetAsync(r_sph.p, 0, (size_t)ns * 16 + 64, st));
+            const Wide8Prims in{c->tri.as<float4>(), c->tri_normal.as<float4>(), c->sph.as<float4>(), c->tri_mat.as<uint32_t>(), c->sph_mat.as<uint32_t>(),
+                                c->tri_has_vmat.as<uint8_t>(), c->prim_id.as<int32_t>()};
+            const Wide8PrimsOut out{r_tri.as<float4>(), r_nrm.as<float4>(), r_sph.as<float4>(), r_mat.as<uint32_t>(), r_smat.as<uint32_t>(), r_vm.as<uint8_t>(),
+                                    r_id.as<int32_t>()};
+            hipLaunchKernelGGL(k_wide8_permute, dim3((n + 255) / 256), dim3(256), 0, st, nt, ns, d_ts.as<uint32_t>(), d_ss.as<uint32_t>(), in, out);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(st));
+            std::swap(c->tri, r_tri); std::swap(c->tri_normal, r_nrm); std::swap(c->tri_mat, r_mat); std::swap(c->tri_has_vmat, r_vm);
+            std::swap(c->sph, r_sph); std::swap(c->sph_mat, r_smat); std::swap(c->prim_id, r_id);
+            DevScene &d = c->sc;
+            d.tri = c->tri.as<float4>(); d.tri_normal = c->tri_normal.as<float4>(); d.tri_mat = c->tri_mat.as<uint32_t>();
+            d.tri_has_vmat = c->tri_has_vmat.as<uint8_t>(); d.sph = c->sph.as<float4>(); d.sph_mat = c->sph_mat.as<uint32_t>();
+            d.prim_id = c->prim_id.as<int32_t>();
+            return MI_OK;
+        };
+        const mi_status rs = body();
+        for (DevBuf *b : tmp) b->release();
+        if (rs != MI_OK) return rs;
+    }
+    const size_t n8 = t.words.size() / 20;
+    for (size_t i = 0; i < n8; i++) { // nothing the kernels follow may point outside the arrays
+        const uint32_t *w = &t.words[20 * i];
+        const uint32_t imask = w[3] >> 24, tmask = w[7] & 0xffu, smask = (w[7] >> 8) & 0xffu;
+        if ((imask & tmask) || (imask & smask) || (tmask & smask) || (w[7] >> 16) || (size_t)w[4] + __builtin_popcount(imask) > n8 || (imask && w[4] <= i) ||
+            (size_t)w[5] + __builtin_popcount(tmask) > nt || (size_t)w[6] + __builtin_popcount(smask) > ns)
+            return fail(MI_ERR_INVALID, "internal: 8-wide node %zu is inconsistent", i);
+    }
+    HIPCHK(c->qnodes.ensure(std::max<size_t>(t.words.size() * 4, 16) + 64));
+    if (n8) HIPCHK(hipMemcpy(c->qnodes.p, t.words.data(), t.words.size() * 4, hipMemcpyHostToDevice));
+    c->sc.qnodes = c->qnodes.as<uint4>();
+    c->sc.treelet_base = 0;
+    c->sc.treelet_count = getenv("MI_TRACER_NO_TREELET") ? 0 : (int32_t)std::min<size_t>(n8, MI_TREELET);
+    c->sc.root_ref = root2 < 0 ? root2 : 0;
+    for (int a = 0; a < 3; a++) { c->sc.qs[a] = 1.0f; c->sc.qb[a] = 0.0f; }
+    c->n_nodes8 = (uint32_t)n8;
+    c->levels8 = t.levels;
+    mi_status pk = pack_shade(c);
+    if (pk != MI_OK) return pk;
+    HIPCHK(hipStreamSynchronize(st));
+    return MI_OK;
+}
+#endif
+
 MI_API mi_status mi_scene_upload(mi_ctx *c, const mi_scene_soa *s) {
     if (!c || !s) return fail(MI_ERR_INVALID, "mi_scene_upload: NULL argument");
     c->has_scene = false; // a rejected or failed upload leaves the context without a scene
@@ -586,7 +664,11 @@ MI_API mi_status mi_scene_upload(mi_ctx *c, const mi_scene_soa *s) {
     if (us != MI_OK) return us;
     c->root_ref2 = s->root_ref;
     c->n_nodes = s->n_nodes;
+#ifdef MI_WIDE8
+    mi_status cs = install_bvh8(c, s->nodes, (uint64_t)s->n_tri + s->n_sph > 1 ? s->root_ref : ~0);
+#else
     mi_status cs = install_bvh4(c, s->nodes, (uint64_t)s->n_tri + s->n_sph > 0 ? s->root_ref : ~0);
+#endif
     if (cs != MI_OK) return cs;
     c->max_stack = stack_need(depth2);
     c->has_scene = true;
@@ -641,6 +723,9 @@ MI_API mi_status mi_scene_download_nodes4(mi_ctx *c, float *nodes4_out, uint32_t
                                           int32_t *root_ref_out, int32_t *treelet_base_out, float grid_out[6]) {
     if (!c) return fail(MI_ERR_INVALID, "mi_scene_download_nodes4: ctx is NULL");
     if (!c->has_scene) return fail(MI_ERR_NO_SCENE, "mi_scene_download_nodes4: no scene uploaded");
+#ifdef MI_WIDE8
+    return fail(MI_ERR_INVALID, "mi_scene_download_nodes4: this library was built with the 8-wide node format");
+#endif
     const uint32_t n = c->sc.qnodes ? (uint32_t)(c->sc.treelet_base + c->sc.treelet_count) : 0u;
     if (n_nodes_out) *n_nodes_out = n;
     if (root_ref_out) *root_ref_out = c->sc.root_ref;
@@ -685,7 +770,11 @@ MI_API mi_status mi_scene_upload_build(mi_ctx *c, const mi_scene_soa *s, const f
     if (n <= 1) { // no interior node: bvh.cu:174-183
         HIPCHK(c->nodes.ensure(16));
         c->root_ref2 = ~0;
+#ifdef MI_WIDE8
+        mi_status cs = install_bvh8(c, nullptr, ~0);
+#else
         mi_status cs = install_bvh4(c, nullptr, ~0);
+#endif
         if (cs != MI_OK) return cs;
         c->max_stack = stack_need(0);
         c->has_scene = true;
@@ -858,6 +947,17 @@ MI_API mi_status mi_scene_upload_build(mi_ctx *c, const mi_scene_soa *s, const f
     if (rs != MI_OK) return rs;
     c->root_ref2 = root2;
     c->n_nodes = n - 1;
+#ifdef MI_WIDE8
+    {   // experiment stage of the 8-wide format: the device-built binary tree is collapsed on the host
+        std::vector<float> h2((size_t)(n - 1) * 16);
+        HIPCHK(hipMemcpy(h2.data(), c->nodes.p, h2.size() * 4, hipMemcpyDeviceToHost));
+        mi_status cs8 = install_bvh8(c, h2.data(), root2);
+        if (cs8 != MI_OK) return cs8;
+        c->max_stack = stack_need(built_depth);
+        c->has_scene = true;
+        return MI_OK;
+    }
+#endif
     c->sc.root_ref = root4; // collapsed on the device above
     c->sc.treelet_base = (int32_t)n4;
     c->sc.treelet_count = treelet_n;
@@ -1321,7 +1421,7 @@ MI_API mi_status mi_render_device_noalloc(mi_ctx *c, const mi_render_params *p, 
     auto carve = [&](size_t bytes) { unsigned char *q = c->ws + off; off += up256(bytes); return q; };
     m.totals = (uint64_t *)carve(kTotals * 8);
     m.counters = (uint32_t *)carve(kCounterWords * 4);
-    m.ovf = (int *)carve(std::max<size_t>(ovf_entries * (size_t)m.egrid * MI_BLOCK * 4, 256));
+    m.ovf = (int *)carve(std::max<size_t>(ovf_entries * (size_t)m.egrid * MI_BLOCK * MI_STACK_ELEM_BYTES, 256));
     const size_t fixed = off;
     // The rest holds one batch: the largest multiple of 64 pixels that fits (per slot: two ray streams of three
     // float4 records, hits, path value, 32 B of history per level; plan_batch has the exact stream sizes).

@@ -1,4 +1,5 @@
-# usage (on the GPU box, from the repo root):  bash profiles/tools/collect.sh <tag> [workload]
+# usage (on the GPU box, from the repo root):  bash profiles/tools/collect.sh <tag> [workload] [variant]
+# (variant, e.g. wide8 with MI_TRACER_LIB_DIR=.../lib8 in the environment: profiles/roofline_pmc.json is left alone)
 # Raw rocprofv3 output goes to gpurun_out/<tag>/; profiles/tools/pmc_to_json.py turns it into the JSON bench.py reads.
 # Passes (each its own run, counters never combined with a trace):
 #   stats : --kernel-trace --stats of `bench.py --streams 1 --steps 10 --warmup 3 --no-cpu-baseline`: every batch on one
@@ -27,6 +28,7 @@ pass sq SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU
 pass sq2 SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_FLAT SQ_ACTIVE_INST_ANY || true
 pass tcc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
 pass tcp TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum
+pass td TD_TD_BUSY_sum TA_TA_BUSY_sum || true
 pass grbm GRBM_GUI_ACTIVE || true
 cd $R
-python profiles/tools/pmc_to_json.py $OUT $TAG $WL
+python profiles/tools/pmc_to_json.py $OUT $TAG $WL $3

@@ -1,7 +1,9 @@
 """Raw rocprofv3 output of profiles/tools/collect.sh -> profiles/<tag>_pmc.json and the entry of this workload in
 profiles/roofline_pmc.json (what bench.py reads for its `roofline` object).
 
-usage: python profiles/tools/pmc_to_json.py <raw dir> <tag> <workload>
+usage: python profiles/tools/pmc_to_json.py <raw dir> <tag> <workload> [variant]
+(`variant`, e.g. "wide8": a pass over another build of the library — profiles/<tag>_pmc.json is written, the roofline
+file bench.py reads is left alone)
 
 Every figure can be recomputed by hand from the committed JSON (raw counters per dispatch are kept):
   dispatches of one frame, in launch order, per batch and level k: k_tail (k >= 1) | k_extend | k_shade; counters and
@@ -84,11 +86,12 @@ def trace_durations(d, levels, batches):
 
 def main():
     raw, tag, workload = sys.argv[1:4]
+    variant = sys.argv[4] if len(sys.argv) > 4 else None
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
     import bench
     levels = bench.WORKLOADS[workload][3] + 2        # rays per path <= depth + 2: launches per batch and kernel
     passes, batches = {}, 1
-    for n in ("fetch", "write", "sq", "sq2", "tcc", "tcp", "grbm"):
+    for n in ("fetch", "write", "sq", "sq2", "tcc", "tcp", "grbm", "td"):
         passes[n], nb = frame_dispatches(counter_rows(os.path.join(raw, n)), levels)
         batches = max(batches, nb)
     dur, frames = trace_durations(os.path.join(raw, "stats"), levels, batches)
@@ -117,6 +120,15 @@ def main():
             r["l2_read_bytes"] = c["TCP_TCC_READ_REQ_sum"] * 64.0
         if "GRBM_GUI_ACTIVE" in c and d_ms > 0:
             r["eff_clock_ghz"] = c["GRBM_GUI_ACTIVE"] / 8.0 / (d_ms * 1e-3) / 1e9
+        if "GRBM_GUI_ACTIVE" in c and c["GRBM_GUI_ACTIVE"] > 0:   # share of the launch the 256 texture-data / texture-address units were busy
+            if "TD_TD_BUSY_sum" in c:
+                r["td_busy"] = c["TD_TD_BUSY_sum"] / 256.0 / (c["GRBM_GUI_ACTIVE"] / 8.0)
+            if "TA_TA_BUSY_sum" in c:
+                r["ta_busy"] = c["TA_TA_BUSY_sum"] / 256.0 / (c["GRBM_GUI_ACTIVE"] / 8.0)
+        if "SQ_INSTS_FLAT" in c:
+            r["flat_insts"] = c["SQ_INSTS_FLAT"]      # wave-level generic loads/stores (node and primitive fetches, hit stores)
+        if "SQ_INSTS_VALU" in c:
+            r["valu_insts"] = c["SQ_INSTS_VALU"]
         recs.append(r)
 
     def summary(kernel):
@@ -132,7 +144,7 @@ def main():
                 "l2_hit": wavg("l2_hit"), "l1_hit": wavg("l1_hit"), "eff_clock_ghz": wavg("eff_clock_ghz"),
                 "by_level": {str(r["level"]): {k: r[k] for k in ("duration_ms", "valu_inst_rate", "lanes_active", "useful_lane_slots_4cyc", "lane_ops",
                                                                      "hbm_bytes", "l2_read_bytes", "l2_hit", "l1_hit", "eff_clock_ghz",
-                                                                     "cycles_per_valu_inst_per_simd") if k in r} for r in rs}}
+                                                                     "cycles_per_valu_inst_per_simd", "td_busy", "ta_busy", "flat_insts", "valu_insts") if k in r} for r in rs}}
 
     n_ext = sum(1 for r in recs if r["kernel"] == "k_extend")
     n_ext *= batches
@@ -141,13 +153,13 @@ def main():
         rays_frame = int(open(os.path.join(raw, "sq.out")).read().split()[-1])
     except (OSError, ValueError, IndexError):
         pass
-    out = {"tag": tag, "workload": workload, "frames_in_trace": frames, "batches_per_frame": batches, "extend_launches_per_frame": n_ext,
+    out = {"tag": tag, "workload": workload, "variant": variant, "frames_in_trace": frames, "batches_per_frame": batches, "extend_launches_per_frame": n_ext,
            "definitions": __doc__.split("Every figure")[1].strip(),
            "summary": {k: summary(k) for k in ("k_extend", "k_shade", "k_tail")}, "dispatches": recs}
     with open(os.path.join("profiles", f"{tag}_pmc.json"), "w") as f:
         json.dump(out, f, indent=1)
-    path = os.path.join("profiles", "roofline_pmc.json")
-    allw = json.load(open(path)) if os.path.exists(path) else {}
+    path = os.path.join("profiles", "roofline_pmc.json" if not variant else f"{tag}_roofline_variant.json")
+    allw = json.load(open(path)) if os.path.exists(path) and not variant else {}
     # what ties the counters to the code they were taken from (bench.pmc_record refuses the record on a mismatch)
     abi = None
     try:
