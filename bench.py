@@ -48,6 +48,7 @@ def main():
     ap.add_argument("--streams", type=int, default=2, choices=[1, 2],
                     help="2 (default): the batches of a frame alternate between two streams; 1: one stream (per-kernel profiling runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="N>1: wait for every step's exchange before the next render starts (default: the exchange of step i runs beside the render of step i+1)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
 
@@ -84,8 +85,13 @@ def main():
     params = P.Context.params(w, h, samples, depth, seed=0, shard=(rank, world), batch_paths=args.batch_paths, one_stream=args.streams == 1)
     p0 = P.Context.params(w, h, samples, depth, seed=0, shard=(0, world))
     stride = P.shard_pixels(p0)  # rank 0 owns the most tiles
-    rgba8 = torch.zeros(stride * 4, dtype=torch.uint8, device=dev)
-    gathered = torch.zeros(world * stride * 4, dtype=torch.uint8, device=dev) if (world > 1 and rank == 0) else None
+    # Two output buffers per rank: step i renders into buffer i % 2, so that for N > 1 the exchange of step i (RCCL's own
+    # stream) runs beside the render of step i + 1 — a shard of a 6-ms frame renders in 1.5-3 ms, the gather of its tiles
+    # and the assembly are 0.1-0.3 ms that need not be serial.
+    rgba8_bufs = [torch.zeros(stride * 4, dtype=torch.uint8, device=dev) for _ in range(2 if world > 1 else 1)]
+    rgba8 = rgba8_bufs[0]
+    gathered_bufs = [torch.zeros(world * stride * 4, dtype=torch.uint8, device=dev) for _ in range(2)] if (world > 1 and rank == 0) else None
+    gathered = gathered_bufs[0] if gathered_bufs else None
     frame = torch.zeros(w * h * 3, dtype=torch.uint8, device=dev) if (world > 1 and rank == 0) else None  # assembled frame stays in HBM, like N=1
     # One explicit (non-default) torch stream carries the renders, the collective's stream dependencies and the
     # assembly: torch's default stream has handle 0, which mi_render_device would read as "the context's own
@@ -98,8 +104,8 @@ def main():
     # only what rank 0 needs; should the backend refuse it, all ranks fall back together to an all-gather.
     use_gather = True
     if world > 1 and args.backend == "gloo":
-        host_local = torch.zeros(stride * 4, dtype=torch.uint8)
-        host_all = [torch.zeros(stride * 4, dtype=torch.uint8) for _ in range(world)] if rank == 0 else None
+        host_local = [torch.zeros(stride * 4, dtype=torch.uint8) for _ in range(2)]
+        host_all = [[torch.zeros(stride * 4, dtype=torch.uint8) for _ in range(world)] for _ in range(2)] if rank == 0 else [None, None]
     if world > 1 and args.backend == "nccl":
         ok = torch.ones(1, device=dev)
         try:
@@ -110,29 +116,55 @@ def main():
             ok.zero_()
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         use_gather = bool(ok.item())
-        if not use_gather and gathered is None:
-            gathered = torch.zeros(world * stride * 4, dtype=torch.uint8, device=dev)
+        if not use_gather and gathered_bufs is None:
+            gathered_bufs = [torch.zeros(world * stride * 4, dtype=torch.uint8, device=dev) for _ in range(2)]
+
+    def exchange_start(b):
+        """Starts the exchange of output buffer b (asynchronously unless --no-overlap); returns the handle finish() takes."""
+        g = gathered_bufs[b] if gathered_bufs else None
+        if args.backend == "gloo":
+            host_local[b].copy_(rgba8_bufs[b])          # rehearsal: tiles staged through the host
+            return dist.gather(host_local[b], host_all[b], dst=0, async_op=True)
+        if use_gather:
+            return dist.gather(rgba8_bufs[b], list(g.view(world, -1).unbind(0)) if rank == 0 else None, dst=0, async_op=True)
+        return dist.all_gather_into_tensor(g, rgba8_bufs[b], async_op=True)
+
+    def exchange_finish(work, b):
+        """Waits for the exchange of buffer b on every rank (its send reads rgba8_bufs[b], which the render after next
+        overwrites) and assembles the frame on rank 0."""
+        work.wait()                                      # nccl: the current stream waits; gloo: the host does
+        if args.backend == "nccl":
+            torch.cuda.current_stream().synchronize()    # the host too, before the buffer is rendered into again
+        if rank == 0:
+            if args.backend == "gloo":
+                gathered_bufs[b].copy_(torch.cat(host_all[b]))
+            ctx.assemble_rgb8_device(params, gathered_bufs[b].data_ptr(), stride, frame.data_ptr(), stream)
+            return frame
+        return None
+
+    pending = []   # [(work, buffer)] exchanges in flight: at most one with the overlap, none without
+    step_no = [0]
 
     def step():
-        st = ctx.render_device(params, None, rgba8.data_ptr(), stream)
+        b = step_no[0] % len(rgba8_bufs)
+        step_no[0] += 1
+        st = ctx.render_device(params, None, rgba8_bufs[b].data_ptr(), stream)   # returns when the shard is rendered
         img = None
         if world > 1:
-            if args.backend == "gloo":
-                host_local.copy_(rgba8)
-                dist.gather(host_local, host_all, dst=0)
-                if rank == 0:
-                    gathered.copy_(torch.cat(host_all))
-            elif use_gather:
-                dist.gather(rgba8, list(gathered.view(world, -1).unbind(0)) if rank == 0 else None, dst=0)
+            while pending:                               # the exchange of the step before ran beside this render
+                img = exchange_finish(*pending.pop(0))
+            work = exchange_start(b)
+            if args.no_overlap:
+                img = exchange_finish(work, b)
             else:
-                dist.all_gather_into_tensor(gathered, rgba8)
-            # every rank: the gather's send still reads rgba8 on RCCL's stream; work.wait() inside dist.gather only
-            # made the current stream wait for it, so block the host here before the next render overwrites rgba8
-            torch.cuda.current_stream().synchronize()
-            if rank == 0:
-                ctx.assemble_rgb8_device(params, gathered.data_ptr(), stride, frame.data_ptr(), stream)
-                img = frame
+                pending.append((work, b))
         return st, img
+
+    def drain():
+        img = None
+        while pending:
+            img = exchange_finish(*pending.pop(0))
+        return img
 
     def fence():
         torch.cuda.synchronize()
@@ -142,6 +174,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    drain()
     fence()
     t0 = time.perf_counter()
     rays = 0
@@ -154,6 +187,8 @@ def main():
         rays_ext += st.rays_extend
         ms_extend += st.ms_extend
         n_ext += st.extend_launches
+    last = drain()                                       # the last step's exchange and assembly belong to the timed region
+    img = last if last is not None else img
     fence()
     dt = time.perf_counter() - t0
 
@@ -184,19 +219,14 @@ def main():
             t_a = time.perf_counter()
             ctx.render_device(params, None, rgba8.data_ptr(), stream)
             t_b = time.perf_counter()
-            if args.backend == "gloo":
-                host_local.copy_(rgba8)
-                dist.gather(host_local, host_all, dst=0)
-            elif use_gather:
-                dist.gather(rgba8, list(gathered.view(world, -1).unbind(0)) if rank == 0 else None, dst=0)
-            else:
-                dist.all_gather_into_tensor(gathered, rgba8)
+            wk = exchange_start(0)
+            wk.wait()
             torch.cuda.synchronize()
             t_c = time.perf_counter()
             if rank == 0:
                 if args.backend == "gloo":
-                    gathered.copy_(torch.cat(host_all))
-                ctx.assemble_rgb8_device(params, gathered.data_ptr(), stride, frame.data_ptr(), stream)
+                    gathered_bufs[0].copy_(torch.cat(host_all[0]))
+                ctx.assemble_rgb8_device(params, gathered_bufs[0].data_ptr(), stride, frame.data_ptr(), stream)
             t_d = time.perf_counter()
             acc = [acc[0] + (t_b - t_a) * 1e3 / 3, acc[1] + (t_c - t_b) * 1e3 / 3, acc[2] + (t_d - t_c) * 1e3 / 3]
         mine = torch.tensor(acc + [float(rays) / args.steps], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
@@ -334,7 +364,8 @@ def main():
                        "bvh_sah_cost": sah_cost, "bvh_build_ms": build.ms_build if build else None,
                        "sharding": f"image tiles 32x32, tile k -> rank k % {world}, BVH replicated; sample-range sharding + sum-reduce not built "
                                    "(a reduce over ranks would round differently from the reference's per-pixel sample order)",
-                       "exchange": None if world == 1 else ("RCCL gather of RGBA8 tiles to rank 0" if args.backend == "nccl" else "REHEARSAL: gloo, all ranks on one GPU"),
+                       "exchange": None if world == 1 else (("RCCL gather of RGBA8 tiles to rank 0" if args.backend == "nccl" else "REHEARSAL: gloo, all ranks on one GPU")
+                                                            + ("" if args.no_overlap else "; the exchange of step i overlaps the render of step i+1 (two output buffers)")),
                        "rays_per_step": rays_all / args.steps, "streams": args.streams},
             "roofline": roof,
         }

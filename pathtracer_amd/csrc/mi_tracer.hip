@@ -448,6 +448,97 @@ static int32_t collapse_bvh4(const float *nodes2, int32_t root2, std::vector<flo
     return root4;
 }
 
+// The same collapse with the seats chosen by dynamic programming instead of the fixed "grandchildren" rule (SAH-optimal
+// widening, Ylitie, Karras, Laine 2017, section 3.1, with the kernels' cost model: a visit costs the same however many of
+// its four seats are filled, so the cost of a tree is the sum of its 4-wide nodes' surface areas).  C[n][i] = least cost of
+// subtree n when it may occupy i + 1 seats of its parent's node: with one seat it must be a 4-wide node of its own
+// (area + best split of FOUR seats among its two children), with more it may hand the seats on to its children.
+static int32_t collapse_bvh4_dp(const float *nodes2, int32_t root2, uint32_t n_nodes2, std::vector<float> &out) {
+    out.clear();
+    if (root2 < 0) return root2;
+    const int W = 4;
+    auto ref_of = [&](int32_t n, int c) { int32_t r; memcpy(&r, nodes2 + 16 * (size_t)n + 12 + c, 4); return r; };
+    auto area_of = [&](int32_t n) {
+        const float *nd = nodes2 + 16 * (size_t)n;
+        float e[3];
+        for (int a = 0; a < 3; a++) e[a] = std::max(nd[3 + a], nd[9 + a]) - std::min(nd[a], nd[6 + a]);
+        return (double)e[0] * e[1] + (double)e[1] * e[2] + (double)e[2] * e[0];
+    };
+    std::vector<double> C((size_t)n_nodes2 * (W - 1), 0.0);
+    std::vector<uint8_t> K((size_t)n_nodes2 * W, 0); // K[n][j]: seats the left child gets when n distributes j seats (j = 2..W)
+    std::vector<int32_t> order, st{root2};
+    order.reserve(n_nodes2);
+    while (!st.empty()) {
+        const int32_t n = st.back(); st.pop_back();
+        order.push_back(n);
+        for (int c = 0; c < 2; c++) if (ref_of(n, c) >= 0) st.push_back(ref_of(n, c));
+    }
+    auto cost = [&](int32_t ref, int seats) { return ref < 0 ? 0.0 : C[(size_t)ref * (W - 1) + (size_t)(std::min(seats, W - 1) - 1)]; };
+    for (size_t q = order.size(); q-- > 0;) { // children before parents
+        const int32_t n = order[q], l = ref_of(n, 0), r = ref_of(n, 1);
+        double dist[W + 1];
+        for (int j = 2; j <= W; j++) {
+            double best = INFINITY; int bk = 1;
+            for (int k = 1; k < j; k++) { const double v = cost(l, k) + cost(r, j - k); if (v < best) { best = v; bk = k; } }
+            dist[j] = best; K[(size_t)n * W + (size_t)(j - 1)] = (uint8_t)bk;
+        }
+        double *Cn = &C[(size_t)n * (W - 1)];
+        Cn[0] = dist[W] + area_of(n);
+        for (int i = 2; i <= W - 1; i++) Cn[i - 1] = std::min(dist[i], Cn[i - 2]);
+    }
+    // emit: a 4-wide node per binary node that ends up with one seat
+    struct Todo { int32_t n2; size_t n4; };
+    std::vector<Todo> todo;
+    auto new_node = [&](int32_t n2) {
+        size_t idx = out.size() / 32;
+        out.resize(out.size() + 32, 0.0f);
+        todo.push_back({n2, idx});
+        return (int32_t)idx;
+    };
+    const int32_t root4 = new_node(root2);
+    float box[4][6]; int32_t ref[4]; int n;
+    // seats of child c of n2 when it is given `seats` seats
+    std::vector<std::pair<std::pair<int32_t, int>, int>> work;
+    while (!todo.empty()) {
+        const Todo t = todo.back(); todo.pop_back();
+        n = 0;
+        work.clear();
+        const int kroot = K[(size_t)t.n2 * W + (W - 1)];
+        work.push_back({{t.n2, 1}, W - kroot});
+        work.push_back({{t.n2, 0}, kroot});
+        while (!work.empty()) {
+            const auto w = work.back(); work.pop_back();
+            const int32_t p = w.first.first; const int c = w.first.second; const int seats = w.second;
+            const float *nd = nodes2 + 16 * (size_t)p;
+            const int32_t r = ref_of(p, c);
+            bool keep = r < 0 || seats == 1;
+            int i = seats;
+            if (!keep) { // which i <= seats defined C[r][seats - 1]: the smallest with the same cost
+                const double *Cr = &C[(size_t)r * (W - 1)];
+                i = std::min(seats, W - 1);
+                while (i > 1 && Cr[i - 1] == Cr[i - 2]) i--;
+                keep = i == 1;
+            }
+            if (keep) { memcpy(box[n], nd + 6 * c, 24); ref[n++] = r; continue; }
+            const int k = K[(size_t)r * W + (size_t)(i - 1)];
+            work.push_back({{r, 1}, i - k});
+            work.push_back({{r, 0}, k});
+        }
+        int32_t out_ref[4];
+        for (int k = 0; k < 4; k++) out_ref[k] = MI_DONE;
+        for (int k = 0; k < n; k++) out_ref[k] = ref[k] < 0 ? ref[k] : new_node(ref[k]);
+        float *o = out.data() + 32 * t.n4;
+        for (int k = 0; k < 4; k++) {
+            for (int a = 0; a < 3; a++) {
+                o[4 * a + k] = k < n ? box[k][a] : 0.0f;
+                o[12 + 4 * a + k] = k < n ? box[k][3 + a] : 0.0f;
+            }
+            memcpy(o + 24 + k, &out_ref[k], 4);
+        }
+    }
+    return root4;
+}
+
 // Copies primitives, materials, ids and camera (everything but the nodes) to the device.
 static mi_status upload_prims(mi_ctx *c, const mi_scene_soa *s) {
     const size_t nt = s->n_tri, ns = s->n_sph;
@@ -545,7 +636,8 @@ static mi_status quantize_nodes4(mi_ctx *c, uint32_t n_total) {
 // Collapses the binary tree (host copy) into the 4-wide tree the kernels walk and uploads it.
 static mi_status install_bvh4(mi_ctx *c, const float *nodes2, int32_t root2) {
     std::vector<float> n4;
-    int32_t root4 = collapse_bvh4(nodes2, root2, n4);
+    const char *how = getenv("MI_TRACER_COLLAPSE");
+    int32_t root4 = (how && !strcmp(how, "dp")) ? collapse_bvh4_dp(nodes2, root2, c->n_nodes, n4) : collapse_bvh4(nodes2, root2, n4);
     // treelet: append copies of the root, its children and grandchildren (breadth first); refs
     // among them point at the copies, the root ref at the root's copy
     c->sc.treelet_base = (int32_t)(n4.size() / 32);
