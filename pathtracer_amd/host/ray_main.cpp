@@ -6,7 +6,7 @@
 // overrides are outside this backend's scope), -c <one of the six face files> loads the
 // cubemap background (CommandLineUI.cu:40-42,66-68).
 // Added: -G <device>, -N <GPUs> (devices -G .. -G + N - 1 render tile shards of the frame in one process, tiles gathered
-// over RCCL), -S <seed>, -B (build the BVH on the GPU).
+// over RCCL), -S <seed>, -B / -H (build the BVH on the GPU / on the host; default: GPU from 100000 primitives on).
 #include <unistd.h>
 
 #include <cmath>
@@ -21,7 +21,7 @@ int main(int argc, char **argv) {
     int size = 512; // TraceUI.h:55
     std::string cubemap;
     int c;
-    while ((c = getopt(argc, argv, "t:r:w:hj:c:s:gq:G:N:S:B")) != -1) {
+    while ((c = getopt(argc, argv, "t:r:w:hj:c:s:gq:G:N:S:BH")) != -1) {
         switch (c) {
             case 't': o.threads = atoi(optarg); // falls through into -r, CommandLineUI.cu:29-33
             case 'r': o.depth = atoi(optarg); break;
@@ -30,13 +30,14 @@ int main(int argc, char **argv) {
             case 'G': o.device = atoi(optarg); break;
             case 'N': o.n_devices = atoi(optarg); break;
             case 'S': o.seed = strtoull(optarg, nullptr, 10); break;
-            case 'B': o.device_bvh = true; break;
+            case 'B': o.device_bvh = 1; break;
+            case 'H': o.device_bvh = 0; break;
             case 'c': cubemap = optarg; break;   // CommandLineUI.cu:40-42
             case 'j': case 'q': case 'g': break;
             default:
                 std::cerr << "usage: " << argv[0] << " [options] [input.ray output.png]\n"
                           << "  -r <#>  recursion level (default 0)\n  -w <#>  image width (default 512)\n"
-                          << "  -s <#>  samples per dimension (default 2)\n  -G <#>  HIP device\n  -N <#>  number of GPUs (starting at -G), one process, tiles gathered over RCCL\n  -S <#>  RNG seed\n  -B      build the BVH on the GPU (PLOC)\n";
+                          << "  -s <#>  samples per dimension (default 2)\n  -G <#>  HIP device\n  -N <#>  number of GPUs (starting at -G), one process, tiles gathered over RCCL\n  -S <#>  RNG seed\n  -B      build the BVH on the GPU (PLOC; the default from 100000 primitives on)\n  -H      build the BVH on the host (binned SAH)\n";
                 return 1;
         }
     }

@@ -259,8 +259,9 @@ inline void put4(std::vector<float> &dst, const V4 &v) { dst.push_back(v.x); dst
 
 } // namespace
 
-void Scene::finalize() {
-    if (finalized_) return;
+void Scene::finalize(bool host_tree) {
+    if (finalized_ && (has_host_tree_ || !host_tree)) return;
+    has_host_tree_ = host_tree;
     const size_t n = prims.size();
     nodes_.clear(); tri_v0_.clear(); tri_uinv_.clear(); tri_vinv_.clear(); tri_ninv_.clear(); tri_normal_.clear();
     sph_cr_.clear(); mats_.clear(); slot_verts_.clear(); tri_mat_.clear(); sph_mat_.clear(); tri_has_vmat_.clear();
@@ -276,9 +277,11 @@ void Scene::finalize() {
     }
     Builder builder(bp);
     int32_t rootRef = 0;
-    if (n > 0) {
+    if (n > 0 && host_tree) {
         Aabb rb;
         rootRef = builder.build(0, n, 0, rb);
+    } else if (n == 1) {
+        rootRef = ~0; // the tree will be built on the device (mi_scene_upload_build): primitives stay in parse order
     }
     bvh_depth_ = builder.maxDepth;
 
@@ -342,7 +345,7 @@ void Scene::finalize() {
     }
     // depth of every node (root = 0) in the first spare word: read only by the
     // instrumented extend kernel (visit histogram per tree level)
-    if (n > 1) {
+    if (n > 1 && host_tree) {
         std::vector<std::pair<int32_t, int32_t>> st{{rootRef, 0}};
         while (!st.empty()) {
             auto [ref, depth] = st.back();
@@ -353,7 +356,7 @@ void Scene::finalize() {
         }
     }
     if (n > 0 && rootRef < 0) rootRef = ~slotOfPos[(size_t)~rootRef];
-    sah_cost_ = (n > 1 && halfArea(sceneBox) > 0) ? builder.sah / halfArea(sceneBox) : 0;
+    sah_cost_ = (n > 1 && host_tree && halfArea(sceneBox) > 0) ? builder.sah / halfArea(sceneBox) : 0;
 
     for (const Material &m : materials) { put4(mats_, m.ke); put4(mats_, m.kd); put4(mats_, m.kr); put4(mats_, m.kt); put4(mats_, m.index); }
 

@@ -69,7 +69,8 @@ public:
 
     // Build the BVH (own binned-SAH builder, one primitive per leaf, child boxes
     // stored in the parent) and flatten everything to SoA.  Idempotent.
-    void finalize();
+    // host_tree = false: flatten the primitives only (parse order, no nodes) for a tree built on the device
+    void finalize(bool host_tree = true);
     // View of the flattened arrays; valid until the scene is modified/destroyed.
     const mi_scene_soa &soa() const { return soa_; }
     // Raw triangle vertices in SLOT order, 3 float4 per triangle (for checkers).
@@ -92,7 +93,7 @@ private:
     mi_scene_soa soa_{};
     int bvh_depth_ = 0;
     double sah_cost_ = 0;
-    bool finalized_ = false;
+    bool finalized_ = false, has_host_tree_ = false;
 };
 
 // .ray text -> Scene (ray_parser.cpp).  Throws ParseError.

@@ -5,6 +5,7 @@
 #include <dirent.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <iostream>
 
@@ -39,8 +40,8 @@ bool Tracer::loadScene(const char *fn) { // tracer.cu:42-85
         return false;
     }
     // Where the reference sorts primitives and builds + flattens its BVH
-    // (tracer.cu:80-83), build this project's BVH and flatten to SoA.
-    scene->finalize();
+    // (tracer.cu:80-83), build this project's BVH (or leave that to the backend) and flatten to SoA.
+    scene->finalize(wantsHostTree(scene->prims.size()));
     return sceneLoaded();
 }
 
@@ -53,7 +54,7 @@ bool Tracer::loadSceneText(const std::string &text) {
         std::cerr << e.message << std::endl;
         return false;
     }
-    scene->finalize();
+    scene->finalize(wantsHostTree(scene->prims.size()));
     return sceneLoaded();
 }
 
@@ -172,9 +173,16 @@ bool HipTracer::cubemapLoaded() {
     return true;
 }
 
+bool HipTracer::wantsHostTree(size_t n_prims) {
+    size_t min_prims = TraceOptions::kDeviceBvhMinPrims;
+    if (const char *e = getenv("PT_DEVICE_BVH_MIN_PRIMS")) min_prims = (size_t)strtoull(e, nullptr, 10); // tuning / tests
+    device_tree_ = opts_.device_bvh > 0 || (opts_.device_bvh < 0 && n_prims >= min_prims);
+    return !device_tree_;
+}
+
 bool HipTracer::sceneLoaded() { // upload replaces Scene::clone, GpuTracer.cu:172-175
     if (!ctx_ && !group_) return false;
-    if (opts_.device_bvh) { // slot vertices are kept as 3 float4 per triangle; the ABI takes 9 floats
+    if (device_tree_) { // slot vertices are kept as 3 float4 per triangle; the ABI takes 9 floats
         const std::vector<float> &v4 = scene->slotVertices();
         std::vector<float> v3(v4.size() / 12 * 9);
         for (size_t t = 0; t < v4.size() / 12; t++)

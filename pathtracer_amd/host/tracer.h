@@ -25,7 +25,11 @@ struct TraceOptions {
     int n_devices = 0;      // > 0: devices device .. device + n_devices - 1 as one mi_group (frame sharded by tile, RGBA8
                             // tiles gathered over RCCL); 0: one context on `device`
     unsigned long long seed = 0;
-    bool device_bvh = false; // build the BVH on the GPU (mi_scene_upload_build) instead of uploading the host-built one
+    // Where the BVH is built: 1 on the GPU (mi_scene_upload_build: PLOC, milliseconds), 0 on the host (binned SAH: its
+    // trees render 1-4 % faster and cost ~2.4 us per primitive: 0.2 s for 82 k, 3.1 s for 1.3 M), -1 (default) on the GPU
+    // from kDeviceBvhMinPrims primitives on, where the host build would cost more than a frame's render many times over.
+    int device_bvh = -1;
+    static constexpr size_t kDeviceBvhMinPrims = 100000;
 };
 
 class Tracer {
@@ -52,6 +56,7 @@ protected:
     virtual unsigned char *frameAlloc(size_t bytes) { return new unsigned char[bytes]; }
     virtual void frameFree(unsigned char *p) { delete[] p; }
     void releaseFrame();                          // derived destructors call it while their frameFree is still reachable
+    virtual bool wantsHostTree(size_t /*n_prims*/) { return true; } // false: the backend builds the tree itself
     virtual bool sceneLoaded() { return true; }
     virtual bool cubemapLoaded() { return true; }
     struct Face { int w = 0, h = 0; std::vector<unsigned char> rgb; };
@@ -86,6 +91,7 @@ public:
     std::string error() const { return error_; }
 
 protected:
+    bool wantsHostTree(size_t n_prims) override;
     bool sceneLoaded() override;
     bool cubemapLoaded() override;
     unsigned char *frameAlloc(size_t bytes) override;   // pinned host memory; ordinary memory if the runtime has none
@@ -99,6 +105,7 @@ private:
     mi_stats stats_{};
     mi_status status_ = MI_OK;
     std::string error_;
+    bool device_tree_ = false;                    // the resident scene's tree was built on the GPU
     unsigned char *pinned_ = nullptr;             // the frame, when it came from mi_host_alloc
 };
 
