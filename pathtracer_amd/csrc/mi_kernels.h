@@ -1203,6 +1203,12 @@ k_tail(DevScene sc, ShardGeom g, uint32_t pix0, uint32_t npix, FastDiv d_npix, i
     lane_idle(L);
     unsigned long long act = 0ull;
     bool more = true; // wave-uniform
+#ifdef MI_TAIL_STATS
+    // Diagnostic build (-DMI_TAIL_STATS, printed with MI_TRACER_DEBUG_LEVELS): is the tail bound by its sparsest waves or by
+    // its longest path?  Per wave: iterations.  Per path (from the moment a lane takes it to its end): iterations that passed,
+    // and iterations in which the path itself advanced (its own dependent chain).
+    uint32_t ts_iters = 0, ts_path_t0 = 0, ts_own = 0, ts_lane_steps = 0, ts_max_elapsed = 0, ts_max_own = 0;
+#endif
     do {              // single back edge, no `continue` (see k_extend)
         const int n_idle = 64 - __popcll(act);
         if (more && (n_idle >= refill_min || act == 0ull)) {
@@ -1225,6 +1231,9 @@ k_tail(DevScene sc, ShardGeom g, uint32_t pix0, uint32_t npix, FastDiv d_npix, i
                     emask = __float_as_uint(d4.w);
                     lane_start(sc, L, xyz(o4), xyz(d4));
                     active = true;
+#ifdef MI_TAIL_STATS
+                    ts_path_t0 = ts_iters; ts_own = 0;
+#endif
                 }
                 rng_next += (uint32_t)n_idle < avail ? (uint32_t)n_idle : avail;
             }
@@ -1233,6 +1242,9 @@ k_tail(DevScene sc, ShardGeom g, uint32_t pix0, uint32_t npix, FastDiv d_npix, i
         const bool want_leaf = active && lane_wants_leaf(L);
         const bool want_node = active && lane_wants_node(L);
         const bool want_shade = active && lane_done(L);
+#ifdef MI_TAIL_STATS
+        ts_iters++;
+#endif
         const int nl = __popcll(__ballot(want_leaf)), nn = __popcll(__ballot(want_node)), ns = __popcll(__ballot(want_shade));
         if (ns > 0 && (ns >= shade_min || (nl == 0 && nn == 0))) {
             bool cont = false;
@@ -1252,9 +1264,16 @@ k_tail(DevScene sc, ShardGeom g, uint32_t pix0, uint32_t npix, FastDiv d_npix, i
                 } else {
                     active = false;
                 }
+#ifdef MI_TAIL_STATS
+                ts_own++; ts_lane_steps++;
+                if (!cont) { ts_max_elapsed = max(ts_max_elapsed, ts_iters - ts_path_t0); ts_max_own = max(ts_max_own, ts_own); }
+#endif
             }
             n_extra += (uint32_t)__popcll(__ballot(cont));
         } else {
+#ifdef MI_TAIL_STATS
+            if (want_leaf || want_node) { ts_own++; ts_lane_steps++; }
+#endif
             // The tail is a latency chain (few rays, whole paths per lane): leaves and nodes
             // both advance in every iteration (1.19 -> 1.04 ms on C3).
             merged_step<false>(sc, L, stack, my_ovf, ovf_stride, nbase, want_leaf, want_node);
@@ -1262,6 +1281,13 @@ k_tail(DevScene sc, ShardGeom g, uint32_t pix0, uint32_t npix, FastDiv d_npix, i
         act = __ballot(active);
     } while (more || act != 0ull);
     if (lane == 0 && n_extra) atomicAdd(extra_rays, (unsigned long long)n_extra);
+#ifdef MI_TAIL_STATS
+    unsigned long long *ts = extra_rays + 41; // totals[48..]
+    if (lane == 0) { atomicMax(&ts[0], (unsigned long long)ts_iters); atomicAdd(&ts[1], (unsigned long long)ts_iters); atomicAdd(&ts[5], 1ull); }
+    atomicMax(&ts[2], (unsigned long long)ts_max_own);
+    atomicMax(&ts[3], (unsigned long long)ts_max_elapsed);
+    atomicAdd(&ts[4], (unsigned long long)ts_lane_steps);
+#endif
 }
 
 // ------------------------------------------------------------------ resolve

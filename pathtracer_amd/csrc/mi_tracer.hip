@@ -1333,7 +1333,7 @@ static mi_status render_batches(mi_ctx *c, const mi_render_params *p, const Shar
     HIPCHK(hipEventRecord(c->ev[1], st));
     HIPCHK(hipStreamSynchronize(st));
     for (int s = 1; s < n_sets; s++) // the two sets' totals are sums, except two maxima (slots 4 and 6)
-        for (int k = 0; k < kTotals; k++) c->h_totals[k] = (k == 4 || k == 6) ? std::max(c->h_totals[k], c->h_totals[s * kTotals + k]) : c->h_totals[k] + c->h_totals[s * kTotals + k];
+        for (int k = 0; k < kTotals; k++) c->h_totals[k] = (k == 4 || k == 6 || k == 48 || k == 50 || k == 51) ? std::max(c->h_totals[k], c->h_totals[s * kTotals + k]) : c->h_totals[k] + c->h_totals[s * kTotals + k];
 #ifdef MI_WAVE_TIMES
     if (const char *wt_path = getenv("MI_TRACER_WAVE_TIMES")) { // the last batch's launches
         std::vector<unsigned long long> h(8 * 8192 * 4);
@@ -1363,6 +1363,13 @@ static mi_status render_batches(mi_ctx *c, const mi_render_params *p, const Shar
             for (int dd = 0; dd < 7; dd++) tot += (double)c->h_totals[10 + dd];
             for (int dd = 0; dd < 7; dd++) fprintf(stderr, "lane slots %-32s %5.1f %%\n", what[dd], 100.0 * (double)c->h_totals[10 + dd] / std::max(tot, 1.0));
         }
+#ifdef MI_TAIL_STATS
+        if (getenv("MI_TRACER_DEBUG_LEVELS"))
+            fprintf(stderr, "k_tail: %llu waves, iterations max %llu mean %.1f; longest path: %llu own steps, %llu iterations from start to end; lane steps %llu = %.1f of 64 lanes\n",
+                    (unsigned long long)c->h_totals[53], (unsigned long long)c->h_totals[48], (double)c->h_totals[49] / std::max<double>(1.0, (double)c->h_totals[53]),
+                    (unsigned long long)c->h_totals[50], (unsigned long long)c->h_totals[51], (unsigned long long)c->h_totals[52],
+                    (double)c->h_totals[52] / std::max<double>(1.0, (double)c->h_totals[49]));
+#endif
         stats->rays_extend = c->h_totals[8];
         if (per_launch) {
             // With two streams the launches of neighbouring batches overlap: these are the launches' own durations
