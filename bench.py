@@ -48,6 +48,7 @@ def main():
     ap.add_argument("--streams", type=int, default=2, choices=[1, 2],
                     help="2 (default): the batches of a frame alternate between two streams; 1: one stream (per-kernel profiling runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sync-steps", action="store_true", help="wait for every frame on the host before the next is enqueued (round 2's loop)")
     ap.add_argument("--no-overlap", action="store_true", help="N>1: wait for every step's exchange before the next render starts (default: the exchange of step i runs beside the render of step i+1)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
@@ -83,6 +84,9 @@ def main():
     sah_cost = ctx.scene_quality()
 
     params = P.Context.params(w, h, samples, depth, seed=0, shard=(rank, world), batch_paths=args.batch_paths, one_stream=args.streams == 1)
+    # the timed loop only ENQUEUES its frames (MI_RENDER_ENQUEUE_ONLY): the GPU goes from one frame to the next without a host
+    # round trip, the fence behind the K steps is the one wait; --sync-steps waits for every frame as round 2 did
+    params_q = P.Context.params(w, h, samples, depth, seed=0, shard=(rank, world), batch_paths=args.batch_paths, one_stream=args.streams == 1, enqueue_only=True)
     p0 = P.Context.params(w, h, samples, depth, seed=0, shard=(0, world))
     stride = P.shard_pixels(p0)  # rank 0 owns the most tiles
     # Two output buffers per rank: step i renders into buffer i % 2, so that for N > 1 the exchange of step i (RCCL's own
@@ -132,9 +136,7 @@ def main():
     def exchange_finish(work, b):
         """Waits for the exchange of buffer b on every rank (its send reads rgba8_bufs[b], which the render after next
         overwrites) and assembles the frame on rank 0."""
-        work.wait()                                      # nccl: the current stream waits; gloo: the host does
-        if args.backend == "nccl":
-            torch.cuda.current_stream().synchronize()    # the host too, before the buffer is rendered into again
+        work.wait()                                      # nccl: the current stream waits (the renders enqueued behind it are ordered with it); gloo: the host does
         if rank == 0:
             if args.backend == "gloo":
                 gathered_bufs[b].copy_(torch.cat(host_all[b]))
@@ -145,10 +147,11 @@ def main():
     pending = []   # [(work, buffer)] exchanges in flight: at most one with the overlap, none without
     step_no = [0]
 
-    def step():
+    def step(wait=False):
         b = step_no[0] % len(rgba8_bufs)
         step_no[0] += 1
-        st = ctx.render_device(params, None, rgba8_bufs[b].data_ptr(), stream)   # returns when the shard is rendered
+        # wait: returns when the shard is rendered, with its stats; otherwise the frame is enqueued on `stream` (None returned)
+        st = ctx.render_device(params if (wait or args.sync_steps) else params_q, None, rgba8_bufs[b].data_ptr(), stream)
         img = None
         if world > 1:
             while pending:                               # the exchange of the step before ran beside this render
@@ -174,19 +177,19 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    ref, _ = step(wait=True)   # untimed: what one step of this rank casts (the image, and with it the ray count, is the same every step)
     drain()
     fence()
     t0 = time.perf_counter()
-    rays = 0
-    rays_ext = 0
-    ms_extend = 0.0
-    n_ext = 0
+    img = None
     for _ in range(args.steps):
-        st, img = step()
-        rays += st.rays_cast
-        rays_ext += st.rays_extend
-        ms_extend += st.ms_extend
-        n_ext += st.extend_launches
+        st, im = step()
+        img = im if im is not None else img
+        if st is not None and st.rays_cast != ref.rays_cast:
+            raise SystemExit(f"step cast {st.rays_cast} rays, the reference step {ref.rays_cast}")
+    rays = ref.rays_cast * args.steps
+    rays_ext = ref.rays_extend * args.steps
+    ms_extend, n_ext = 0.0, 0
     last = drain()                                       # the last step's exchange and assembly belong to the timed region
     img = last if last is not None else img
     fence()
@@ -366,11 +369,22 @@ def main():
                                    "(a reduce over ranks would round differently from the reference's per-pixel sample order)",
                        "exchange": None if world == 1 else (("RCCL gather of RGBA8 tiles to rank 0" if args.backend == "nccl" else "REHEARSAL: gloo, all ranks on one GPU")
                                                             + ("" if args.no_overlap else "; the exchange of step i overlaps the render of step i+1 (two output buffers)")),
-                       "rays_per_step": rays_all / args.steps, "streams": args.streams},
+                       "rays_per_step": rays_all / args.steps, "streams": args.streams,
+                       "steps_enqueued_without_host_wait": not args.sync_steps},
             "roofline": roof,
         }
         if phases:
             out["phases"] = phases
+        if world == 1 and not args.sync_steps:
+            # the same K steps with a host wait after every frame (what a caller that needs each frame's stats pays)
+            fence()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                ctx.render_device(params, None, rgba8.data_ptr(), stream)
+            fence()
+            out["value_sync_each_step"] = {"value": rays_all / (time.perf_counter() - t1) / 1e6, "unit": "Mrays/s",
+                                           "what": "mi_render_device waits for every frame before the next is enqueued; `value` enqueues the K frames "
+                                                   "(MI_RENDER_ENQUEUE_ONLY) and waits once, at the fence that closes the timed region"}
         if world == 1:
             # the Tracer boundary hands back HOST bytes (HipTracer::traceImage -> mi_render): the same frame with the RGB8 copy to a
             # pageable host buffer, PCIe-inclusive; never `value`

@@ -128,6 +128,13 @@ typedef struct mi_render_params {
  * 4 per level and batch, ~0.15 ms of a 6.5 ms frame.  They are recorded only on request (or with
  * MI_TRACER_DEBUG_LEVELS in the environment); without this bit those fields are 0 and ms_other = ms_total. */
 #define MI_RENDER_LAUNCH_TIMES 2
+/* mi_render_device only, with stats == NULL: the frame is ENQUEUED on `stream` and the call returns without waiting for it
+ * (a caller that renders frame after frame — an animation, a progressive viewer, bench.py's timed loop — keeps the GPU
+ * busy between frames instead of paying a host round trip per frame: ~0.16 ms of a 6-ms frame).  The outputs are complete
+ * when `stream` has run dry (hipStreamSynchronize / an event of the caller's); frames enqueued on one stream run in order.
+ * No counterpart in the reference (GpuTracer.cu:180 synchronises the device after its one kernel).  MI_ERR_INVALID with
+ * stats != NULL or with count_work. */
+#define MI_RENDER_ENQUEUE_ONLY 4
 
 typedef struct mi_stats {
     uint64_t rays_cast;      /* closest-hit queries issued (primary + bounce)       */

@@ -24,6 +24,7 @@ class MiError(RuntimeError):
 MI_OK, MI_ERR_INVALID, MI_ERR_NO_DEVICE, MI_ERR_HIP, MI_ERR_NO_SCENE, MI_ERR_OOM = range(6)
 MI_RENDER_ONE_STREAM = 1
 MI_RENDER_LAUNCH_TIMES = 2
+MI_RENDER_ENQUEUE_ONLY = 4
 
 c_float_p = C.POINTER(C.c_float)
 c_u32_p = C.POINTER(C.c_uint32)

@@ -1416,6 +1416,8 @@ static mi_status render_device_impl(mi_ctx *c, const mi_render_params *p, void *
     ShardGeom g;
     mi_status gs = make_geom(p, g);
     if (gs != MI_OK) return gs;
+    const bool enqueue_only = (p->flags & MI_RENDER_ENQUEUE_ONLY) != 0;
+    if (enqueue_only && (stats || p->count_work || post)) return fail(MI_ERR_INVALID, "MI_RENDER_ENQUEUE_ONLY needs stats == NULL, no count_work, and mi_render_device");
     HIPCHK(hipSetDevice(c->device));
     hipStream_t st = stream_v ? (hipStream_t)stream_v : c->stream;
     const int64_t local = shard_pixels(g);
@@ -1457,7 +1459,11 @@ static mi_status render_device_impl(mi_ctx *c, const mi_render_params *p, void *
         mi_status ps = plan_batch(c, npix_b, spp, p->depth, bp);
         if (ps != MI_OK) return ps;
         hipError_t ae = hipSuccess;
-        auto grow = [&](DevBuf &b, size_t bytes) { if (ae == hipSuccess) ae = b.ensure(bytes); };
+        bool drained = false; // a buffer that must grow is freed first: frames an enqueue-only call left running may still use it
+        auto grow = [&](DevBuf &b, size_t bytes) {
+            if (ae == hipSuccess && bytes > b.bytes && !drained) { ae = hipDeviceSynchronize(); drained = true; }
+            if (ae == hipSuccess) ae = b.ensure(bytes);
+        };
         for (int s = 0; s < n_sets; s++) {
             auto &pb = c->pb[s];
             for (int i = 0; i < 2; i++) { grow(pb.ray_o[i], bp.stream_cap * 16); grow(pb.ray_d[i], bp.stream_cap * 16); grow(pb.thr[i], bp.stream_cap * 16); }
@@ -1489,7 +1495,7 @@ static mi_status render_device_impl(mi_ctx *c, const mi_render_params *p, void *
         m.egrid = n_sets > 1 ? c->n_cu * c->extend_wg_two : extend_grid(c);
         m.egrid0 = c->n_cu * c->extend_wg_primary; m.tgrid = c->n_cu * c->tail_wg_per_cu;
     }
-    return render_batches(c, p, g, bp, sets, n_sets, d_rgba_mean, d_rgba8, st, stats, true, true, post);
+    return render_batches(c, p, g, bp, sets, n_sets, d_rgba_mean, d_rgba8, st, stats, !enqueue_only, !enqueue_only, post);
 }
 
 // ---- the entry point that allocates nothing (workspace: see `scratch` at the top of this file) ----------
@@ -1559,6 +1565,7 @@ MI_API mi_status mi_render_device_noalloc(mi_ctx *c, const mi_render_params *p, 
 MI_API mi_status mi_render(mi_ctx *c, const mi_render_params *p, float *rgba_mean_out, uint8_t *rgb8_out, mi_stats *stats) {
     if (!c) return fail(MI_ERR_INVALID, "ctx is NULL");
     if (!c->has_scene) return fail(MI_ERR_NO_SCENE, "mi_render: no scene uploaded");
+    if (p && (p->flags & MI_RENDER_ENQUEUE_ONLY)) return fail(MI_ERR_INVALID, "mi_render: outputs in host memory need the wait (MI_RENDER_ENQUEUE_ONLY is for mi_render_device)");
     ShardGeom g;
     mi_status gs = make_geom(p, g);
     if (gs != MI_OK) return gs;

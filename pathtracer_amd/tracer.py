@@ -89,9 +89,11 @@ class Context:
         return ids
 
     @staticmethod
-    def params(width, height, samples, depth, seed=0, tile=(0, 0), shard=(0, 1), batch_paths=0, count_work=False, one_stream=False, launch_times=False):
+    def params(width, height, samples, depth, seed=0, tile=(0, 0), shard=(0, 1), batch_paths=0, count_work=False, one_stream=False, launch_times=False,
+               enqueue_only=False):
         return N.RenderParams(width, height, samples, depth, seed, tile[0], tile[1], shard[0], shard[1], batch_paths,
-                              1 if count_work else 0, (N.MI_RENDER_ONE_STREAM if one_stream else 0) | (N.MI_RENDER_LAUNCH_TIMES if launch_times else 0))
+                              1 if count_work else 0, (N.MI_RENDER_ONE_STREAM if one_stream else 0) | (N.MI_RENDER_LAUNCH_TIMES if launch_times else 0)
+                              | (N.MI_RENDER_ENQUEUE_ONLY if enqueue_only else 0))
 
     def render(self, params, want_mean=True, want_rgb8=True, rgb_out=None):
         """Host-buffer render.  Returns (mean float32[h,w,4] | None, rgb8 uint8[h,w,3] | None, Stats);
@@ -110,6 +112,11 @@ class Context:
         return mean, rgb, st
 
     def render_device(self, params, d_mean_ptr, d_rgba8_ptr, stream=None):
+        """mi_render_device.  With params built with enqueue_only=True the frame is only enqueued on `stream` (the
+        caller synchronises) and None is returned instead of the Stats."""
+        if params.flags & N.MI_RENDER_ENQUEUE_ONLY:
+            N.check(N.mi.mi_render_device(self._h, C.byref(params), d_mean_ptr, d_rgba8_ptr, stream, None))
+            return None
         st = N.Stats()
         N.check(N.mi.mi_render_device(self._h, C.byref(params), d_mean_ptr, d_rgba8_ptr, stream, C.byref(st)))
         return st

@@ -53,3 +53,41 @@ def test_tracer_pins_its_frame_buffer_across_setups(scenes_small):
             t.wait_render()
         _, orgb, _ = O.render(sc, P.Context.params(w, h, 2, 2, seed=5))
         assert np.array_equal(t.get_buffer(), orgb)
+
+
+def test_enqueue_only_frames_match_waited_frames(ctx, scenes_small):
+    # MI_RENDER_ENQUEUE_ONLY: frames enqueued back to back on one stream, one wait at the end (bench.py's timed loop); growing
+    # batches in between (a larger frame after a smaller one) must not free buffers a running frame still uses
+    import ctypes as C
+    import torch
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(device=dev)
+    sc = scenes_small["glass"]
+    ctx.upload(sc)
+    outs, wants = [], []
+    for width, s, d in ((64, 1, 3), (200, 2, 8), (96, 2, 5), (333, 2, 8)):
+        w, h = sc.image_size(width)
+        p = P.Context.params(w, h, s, d, seed=13)
+        n = P.shard_pixels(p)
+        want = torch.zeros((n, 4), dtype=torch.uint8, device=dev)
+        ctx.render_device(p, None, want.data_ptr(), stream.cuda_stream)
+        wants.append(want)
+    c2 = P.Context(0)                                                      # a fresh context: its buffers start empty and must grow
+    c2.upload(sc)
+    for width, s, d in ((64, 1, 3), (200, 2, 8), (96, 2, 5), (333, 2, 8)):
+        w, h = sc.image_size(width)
+        pq = P.Context.params(w, h, s, d, seed=13, enqueue_only=True)
+        out = torch.full((P.shard_pixels(pq), 4), 3, dtype=torch.uint8, device=dev)
+        assert c2.render_device(pq, None, out.data_ptr(), stream.cuda_stream) is None
+        outs.append(out)
+    stream.synchronize()
+    for out, want in zip(outs, wants):
+        assert torch.equal(out, want)
+    st = N.Stats()
+    pq = P.Context.params(32, 32, 1, 1, enqueue_only=True)
+    assert N.mi.mi_render_device(c2._h, C.byref(pq), None, outs[0].data_ptr(), None, C.byref(st)) == N.MI_ERR_INVALID   # no stats without a wait
+    pc = P.Context.params(32, 32, 1, 1, enqueue_only=True, count_work=True)
+    assert N.mi.mi_render_device(c2._h, C.byref(pc), None, outs[0].data_ptr(), None, None) == N.MI_ERR_INVALID
+    rgb = np.zeros((32, 32, 3), np.uint8)
+    assert N.mi.mi_render(c2._h, C.byref(pq), None, rgb.ctypes.data, None) == N.MI_ERR_INVALID                          # host outputs need the wait
+    c2.close()
