@@ -244,8 +244,8 @@ mi_status mi_render_device(mi_ctx *ctx, const mi_render_params *params,
  * makes no hipMalloc / hipFree / event or stream creation: all per-batch path state (ray streams, hits,
  * history, path values, counters, traversal overflow stacks) lives in one static device array of
  * mi_noalloc_workspace_bytes() = 64 MiB that every GPU running this library holds until the process ends.
- * The frame is rendered in as many batches as that takes (C3 at 1080p: 200+ batches, several times slower
- * than mi_render_device: it is the entry point for those who cannot call the other).
+ * The frame is rendered in as many batches as that takes (C3 at 1080p: 252 batches, 87 ms against
+ * 6 ms through mi_render_device: it is the entry point for those who cannot call the other).
  * Limits: MI_ERR_INVALID with a message naming the sizes when even the smallest batch (64 pixels x
  * samples_per_dim^2 paths at `depth`, plus the overflow stacks the resident tree needs) does not fit —
  * e.g. depth 5 allows samples_per_dim up to ~40, depth 62 up to ~16; count_work is not supported.
