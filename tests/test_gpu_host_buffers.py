@@ -83,6 +83,29 @@ def test_enqueue_only_frames_match_waited_frames(ctx, scenes_small):
     stream.synchronize()
     for out, want in zip(outs, wants):
         assert torch.equal(out, want)
+    # frames large enough for the context's two streams: three in a row into three buffers, one wait; a consumer's stream
+    # ordered behind them by an event of the caller's
+    sc2 = scenes_small["cornell"]
+    c2.upload(sc2)
+    w, h = sc2.image_size(512)
+    p = P.Context.params(w, h, 6, 5, seed=2)
+    n = P.shard_pixels(p)
+    want = torch.zeros((n, 4), dtype=torch.uint8, device=dev)
+    stw = c2.render_device(p, None, want.data_ptr(), stream.cuda_stream)
+    assert stw.batches == 2
+    pq = P.Context.params(w, h, 6, 5, seed=2, enqueue_only=True)
+    bufs = [torch.full((n, 4), 5, dtype=torch.uint8, device=dev) for _ in range(3)]
+    for bf in bufs:
+        c2.render_device(pq, None, bf.data_ptr(), stream.cuda_stream)
+    consumer = torch.cuda.Stream(device=dev)
+    consumer.wait_stream(stream)
+    with torch.cuda.stream(consumer):
+        copies = [bf.clone() for bf in bufs]                               # ordered behind all three frames by the flush
+    consumer.synchronize()
+    for cp in copies:
+        assert torch.equal(cp, want)
+    st2 = c2.render_device(p, None, bufs[0].data_ptr(), stream.cuda_stream)   # a waiting call closes whatever is open
+    assert st2.rays_cast == stw.rays_cast and torch.equal(bufs[0], want)
     st = N.Stats()
     pq = P.Context.params(32, 32, 1, 1, enqueue_only=True)
     assert N.mi.mi_render_device(c2._h, C.byref(pq), None, outs[0].data_ptr(), None, C.byref(st)) == N.MI_ERR_INVALID   # no stats without a wait
