@@ -763,6 +763,10 @@ MI_API mi_status mi_scene_upload(mi_ctx *c, const mi_scene_soa *s) {
 #endif
     if (cs != MI_OK) return cs;
     c->max_stack = stack_need(depth2);
+#ifndef MI_WIDE8
+    // the dynamic-programming collapse may spend a 4-wide level on a single binary level: no better bound than the tree's depth
+    if (const char *how = getenv("MI_TRACER_COLLAPSE")) if (!strcmp(how, "dp")) c->max_stack = std::min(MI_MAX_STACK, 3 * depth2 + 3);
+#endif
     c->has_scene = true;
     return MI_OK;
 }
