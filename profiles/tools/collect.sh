@@ -16,8 +16,11 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/stats -o run --output-format csv -- python $R/bench.py --streams 1 --steps 10 --warmup 3 --no-cpu-baseline --workload $WL > $OUT/bench_profiled_one_stream.json 2> $OUT/stats.log
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/stats2 -o run --output-format csv -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --workload $WL > $OUT/bench_profiled.json 2> $OUT/stats2.log
+stats_passes() {
+    timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/stats -o run --output-format csv -- python $R/bench.py --streams 1 --steps 10 --warmup 3 --no-cpu-baseline --workload $WL > $OUT/bench_profiled_one_stream.json 2> $OUT/stats.log
+    timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/stats2 -o run --output-format csv -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --workload $WL > $OUT/bench_profiled.json 2> $OUT/stats2.log
+}
+stats_passes
 pass() { # name, counters...
     n=$1; shift
     timeout -s KILL 180 rocprofv3 --pmc "$@" -d $OUT/$n -o run --output-format csv -- python $R/profiles/tools/one_frame.py $WL > $OUT/$n.out 2> $OUT/$n.log
@@ -32,3 +35,12 @@ pass td TD_TD_BUSY_sum TA_TA_BUSY_sum || true
 pass grbm GRBM_GUI_ACTIVE || true
 cd $R
 python profiles/tools/pmc_to_json.py $OUT $TAG $WL $3
+# The two bench lines above were printed while profiles/roofline_pmc.json still described the previous sources (their
+# roofline is withheld as stale after a kernel edit): print them again, now against the pass just converted, and convert
+# once more so that the per-level durations in the JSON are those of the kernel_stats files kept beside it.
+if [ -z "$3" ]; then
+    cd /tmp
+    stats_passes
+    cd $R
+    python profiles/tools/pmc_to_json.py $OUT $TAG $WL
+fi
