@@ -39,8 +39,9 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="C3-blob82k-1080p-16spp", choices=sorted(WORKLOADS))
-    ap.add_argument("--bvh", default="host", choices=["host", "device"],
-                    help="host: binned-SAH tree built by libpt_host (default); device: built by mi_scene_upload_build (PLOC; MI_TRACER_BUILDER=lbvh for the Karras LBVH)")
+    ap.add_argument("--bvh", default="device", choices=["host", "device"],
+                    help="device (default): built by mi_scene_upload_build (top-down binned SAH; MI_TRACER_BUILDER=ploc | lbvh for the other builders); "
+                         "host: the same tree built by libpt_host")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the N>1 path with several ranks on ONE GPU (tiles staged through the host); never a result")
     ap.add_argument("--check", action="store_true", help="N>1: rank 0 also renders the whole frame alone and compares the assembled frame byte for byte")
@@ -363,7 +364,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": args.workload, "image": [w, h], "samples_per_dim": samples, "depth": depth,
                        "primitives": scene.n_prims,
-                       "bvh": ("device " + (os.environ.get("MI_TRACER_BUILDER") or "ploc").upper()) if build else "host binned SAH", "bvh_depth": build.depth if build else scene.bvh_depth,
+                       "bvh": ("device " + {"sah": "binned SAH", "ploc": "PLOC", "lbvh": "LBVH"}[device_builder()]) if build else "host binned SAH", "bvh_depth": build.depth if build else scene.bvh_depth,
                        "bvh_sah_cost": sah_cost, "bvh_build_ms": build.ms_build if build else None,
                        "sharding": f"image tiles 32x32, tile k -> rank k % {world}, BVH replicated; sample-range sharding + sum-reduce not built "
                                    "(a reduce over ranks would round differently from the reference's per-pixel sample order)",
@@ -440,6 +441,10 @@ def main():
 KERNEL_SOURCES = ("pathtracer_amd/csrc/mi_kernels.h", "pathtracer_amd/csrc/mi_tracer.hip", "pathtracer_amd/csrc/mi_bvh_build.h")
 
 
+def device_builder():
+    return os.environ.get("MI_TRACER_BUILDER") or "sah"
+
+
 def kernel_source_sha256(root=ROOT):
     """sha256 over the device sources the render kernels are compiled from, in KERNEL_SOURCES order.  pmc_to_json.py
     stores it with every PMC pass; pmc_record() recomputes it, so counters of OTHER code are never divided by this
@@ -461,7 +466,7 @@ def pmc_record(workload, world, bvh, rays_cast_frame=None, root=ROOT):
     ABI version, or when the frame it profiled cast another number of rays than this run's frame (other tuning
     knobs, batch sizes or scene)."""
     path = os.path.join(root, "profiles", "roofline_pmc.json")
-    if bvh != "host" or not os.path.exists(path):
+    if (bvh != "host" and device_builder() != "sah") or not os.path.exists(path): # the device's SAH build is the host's tree; PLOC / LBVH trees are not
         return None, None
     with open(path) as f:
         rec = json.load(f).get(workload)

@@ -168,8 +168,10 @@ mi_status mi_scene_upload(mi_ctx *ctx, const mi_scene_soa *scene);
  * root_ref are ignored, and tri_verts gives the three vertices of every triangle slot (float[9*n_tri], HOST; the boxes of
  * geometry.h:13-29 need them — the precomputed uInv/vInv/nInv do not contain them).
  * Replaces the host-side BoundedVolumeHierarchy::construct + flatten (bvh.cu:66-172,
- * 239-369) with PLOC (parallel locally-ordered clustering over the Morton
- * order; MI_TRACER_BUILDER=lbvh in the environment selects a plain Karras LBVH).  The
+ * 239-369) with a top-down binned-SAH build (16 bins, three axes: the algorithm of this project's host
+ * builder carried out level by level on the GPU; it arrives at the same tree, node for node.  MI_TRACER_BUILDER=ploc
+ * in the environment selects parallel locally-ordered clustering over the Morton order instead — half the build time,
+ * trees that render 1-4 % slower — and =lbvh a plain Karras LBVH).  The
  * primitive records are gathered into tree order on the device: the slots the resident tree
  * refers to are NOT the caller's (mi_scene_download_prim_ids maps them to primitive ids).  The rendered image does not depend on which tree is used (exact-t ties
  * are resolved by primitive id and child boxes are padded, see mi_scene_soa.prim_id), so

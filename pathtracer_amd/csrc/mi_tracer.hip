@@ -880,12 +880,17 @@ MI_API mi_status mi_scene_upload_build(mi_ctx *c, const mi_scene_soa *s, const f
     }
     hipStream_t st = c->stream;
     // build-time scratch, released when the build is done (the build is not a hot path)
+    DevBuf td_box_a, td_box_b, td_idx_a, td_idx_b, td_node_a, td_node_b, td_nodes, td_small, td_bins, td_cnt;
     DevBuf verts, pb, sbox, keys_a, keys_b, vals_a, vals_b, children, par_n, par_l, nb, height, flags, area, cub_tmp, ref_a, ref_t, box_a, box_t, r_tri, r_nrm, r_mat, r_vm, r_sph, r_smat, r_id;
-    DevBuf *tmp[] = {&r_tri, &r_nrm, &r_mat, &r_vm, &r_sph, &r_smat, &r_id, &verts, &pb, &sbox, &keys_a, &keys_b, &vals_a, &vals_b, &children, &par_n, &par_l, &nb, &height, &flags, &area, &cub_tmp, &ref_a, &ref_t, &box_a, &box_t};
+    DevBuf *tmp[] = {&td_box_a, &td_box_b, &td_idx_a, &td_idx_b, &td_node_a, &td_node_b, &td_nodes, &td_small, &td_bins, &td_cnt, &r_tri, &r_nrm, &r_mat, &r_vm, &r_sph, &r_smat, &r_id, &verts, &pb, &sbox, &keys_a, &keys_b, &vals_a, &vals_b, &children, &par_n, &par_l, &nb, &height, &flags, &area, &cub_tmp, &ref_a, &ref_t, &box_a, &box_t};
     mi_status rs = MI_OK;
     // MI_TRACER_BUILDER=lbvh selects the plain Karras LBVH; the default is PLOC over the same Morton order
+    // MI_TRACER_BUILDER: sah (default) = top-down binned SAH, the host builder's tree; ploc = parallel locally-ordered
+    // clustering over the Morton order (half the build time, trees that render 1-4 % slower); lbvh = plain Karras LBVH
     const char *builder = getenv("MI_TRACER_BUILDER");
-    const bool use_ploc = !(builder && !strcmp(builder, "lbvh"));
+    const bool use_sah = !builder || !*builder || !strcmp(builder, "sah");
+    const bool use_ploc = !use_sah && !strcmp(builder, "ploc");
+    if (!use_sah && !use_ploc && strcmp(builder, "lbvh")) return fail(MI_ERR_INVALID, "MI_TRACER_BUILDER=%s: expected sah, ploc or lbvh", builder);
     int32_t root2 = 0, root4 = 0;
     uint32_t n4 = 0;
     int treelet_n = 0, built_depth = 0;
@@ -926,11 +931,14 @@ MI_API mi_status mi_scene_upload_build(mi_ctx *c, const mi_scene_soa *s, const f
         HIPCHK(hipMemsetAsync(area.p, 0, 8, st));
         hipLaunchKernelGGL(k_build_prim_bounds, grid, block, 0, st, s->n_tri, s->n_sph, verts.as<float>(), c->sph.as<float4>(), pb.as<BuildBox>(),
                            sbox.as<float>());
-        hipLaunchKernelGGL(k_build_morton, grid, block, 0, st, n, pb.as<BuildBox>(), sbox.as<float>(), keys_a.as<uint64_t>(), vals_a.as<uint32_t>());
-        HIPCHK(hipcub::DeviceRadixSort::SortPairs(cub_tmp.p, cub_bytes, keys_a.as<uint64_t>(), keys_b.as<uint64_t>(), vals_a.as<uint32_t>(),
-                                                  vals_b.as<uint32_t>(), (int)n, 0, 62, st));
-        // primitives into Morton order (per class), prim_id and boxes along with them
-        {
+        if (!use_sah) {
+            hipLaunchKernelGGL(k_build_morton, grid, block, 0, st, n, pb.as<BuildBox>(), sbox.as<float>(), keys_a.as<uint64_t>(), vals_a.as<uint32_t>());
+            HIPCHK(hipcub::DeviceRadixSort::SortPairs(cub_tmp.p, cub_bytes, keys_a.as<uint64_t>(), keys_b.as<uint64_t>(), vals_a.as<uint32_t>(),
+                                                      vals_b.as<uint32_t>(), (int)n, 0, 62, st));
+        }
+        // primitives into the order vals_b names (position i takes slot vals_b[i]; per class), prim_id and boxes along with
+        // them; vals_b[i] becomes the new slot.  Morton order before PLOC / LBVH, tree order after the top-down build.
+        auto permute_prims = [&]() -> mi_status {
             const size_t nt = s->n_tri, ns = s->n_sph;
             HIPCHK(r_tri.ensure(nt * 48 + 16));
             HIPCHK(r_nrm.ensure(std::max<size_t>(nt * 16, 16)));
@@ -955,7 +963,9 @@ MI_API mi_status mi_scene_upload_build(mi_ctx *c, const mi_scene_soa *s, const f
             d.tri_has_vmat = c->tri_has_vmat.as<uint8_t>(); d.sph = c->sph.as<float4>(); d.sph_mat = c->sph_mat.as<uint32_t>();
             d.prim_id = c->prim_id.as<int32_t>();
             HIPCHK(hipMemsetAsync(flags.p, 0, (size_t)n * 4, st)); // the fit's arrival flags start at zero
-        }
+            return MI_OK;
+        };
+        if (!use_sah) { mi_status ps = permute_prims(); if (ps != MI_OK) return ps; }
         // padding needs the scene diagonal: one small read-back in the middle of the build
         float hb[8];
         HIPCHK(hipMemcpyAsync(hb, sbox.p, 32, hipMemcpyDeviceToHost, st));
@@ -963,7 +973,79 @@ MI_API mi_status mi_scene_upload_build(mi_ctx *c, const mi_scene_soa *s, const f
         const double dx = (double)hb[3] - hb[0], dy = (double)hb[4] - hb[1], dz = (double)hb[5] - hb[2];
         const float pad = 1e-5f * (float)std::sqrt(dx * dx + dy * dy + dz * dz) + 1e-30f; // as the host flattener
         const dim3 ngrid((n - 1 + MI_BUILD_BLOCK - 1) / MI_BUILD_BLOCK);
-        if (use_ploc) {
+        if (use_sah) {
+            // top-down binned SAH (mi_bvh_build.h): one tree level per round while nodes hold more than MI_TD_SMALL
+            // primitives, then one wave per remaining node
+            const size_t cap_top = (size_t)n / 32 + 64, cap_small = (size_t)n / 2 + 1, cap_level = (size_t)n / 64 + 2;
+            HIPCHK(td_box_a.ensure((size_t)n * sizeof(BuildBox)));
+            HIPCHK(td_box_b.ensure((size_t)n * sizeof(BuildBox)));
+            HIPCHK(td_idx_a.ensure((size_t)n * 4));
+            HIPCHK(td_idx_b.ensure((size_t)n * 4));
+            HIPCHK(td_node_a.ensure((size_t)n * 4));
+            HIPCHK(td_node_b.ensure((size_t)n * 4));
+            HIPCHK(td_nodes.ensure(cap_top * sizeof(TdNode)));
+            HIPCHK(td_small.ensure(cap_small * sizeof(TdSmall)));
+            HIPCHK(td_bins.ensure(cap_level * MI_TD_BIN_WORDS * 4));
+            HIPCHK(td_cnt.ensure(64));
+            uint32_t cnt_h[4] = {0u, 0u, 0u, 0u}; // [1] nodes of the next level, [2] small jobs, [3] the root's index
+            uint32_t level_first = 0, level_n = 0;
+            if (n > MI_TD_SMALL) {
+                TdNode root{};
+                root.begin = 0; root.count = n; root.parent = -1; root.depth = 0;
+                HIPCHK(hipMemcpyAsync(td_nodes.p, &root, sizeof root, hipMemcpyHostToDevice, st));
+                level_n = 1;
+            } else {
+                const TdSmall job{0u, n, -1, 0u};
+                HIPCHK(hipMemcpyAsync(td_small.p, &job, sizeof job, hipMemcpyHostToDevice, st));
+                cnt_h[2] = 1u;
+            }
+            HIPCHK(hipMemcpyAsync(td_cnt.p, cnt_h, 16, hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(k_td_init, grid, block, 0, st, n, pb.as<BuildBox>(), td_box_a.as<BuildBox>(), td_idx_a.as<uint32_t>(), td_node_a.as<uint32_t>(),
+                               level_n ? 0u : MI_TD_NONE);
+            HIPCHK(hipStreamSynchronize(st)); // root / job / cnt_h are stack memory
+            DevBuf *bx = &td_box_a, *bx2 = &td_box_b, *ix = &td_idx_a, *ix2 = &td_idx_b, *nx = &td_node_a, *nx2 = &td_node_b;
+            for (int level = 0; level_n > 0; level++) {
+                if (level > 36 + 32) return fail(MI_ERR_HIP, "top-down build did not end");
+                if (level_n > cap_level || (size_t)level_first + level_n > cap_top) return fail(MI_ERR_HIP, "top-down build: %u nodes on level %d", level_n, level);
+                const uint32_t next_first = level_first + level_n;
+                HIPCHK(hipMemsetAsync(td_bins.p, 0, (size_t)level_n * MI_TD_BIN_WORDS * 4, st));
+                HIPCHK(hipMemsetAsync(td_cnt.as<uint32_t>() + 1, 0, 4, st));
+                // positions per wave: 64 where nodes are small, up to 1024 where they are large (fewer, fuller flushes of the partial sums)
+                uint32_t chunks = 1;
+                while (chunks < 16u && (uint64_t)level_n * 4096u * chunks < n) chunks *= 2;
+                const dim3 cgrid((n + MI_BUILD_BLOCK * chunks - 1) / (MI_BUILD_BLOCK * chunks));
+                hipLaunchKernelGGL(k_td_bounds, cgrid, block, 0, st, n, bx->as<BuildBox>(), nx->as<uint32_t>(), td_nodes.as<TdNode>(), chunks);
+                hipLaunchKernelGGL(k_td_bin, cgrid, block, 0, st, n, bx->as<BuildBox>(), nx->as<uint32_t>(), td_nodes.as<TdNode>(), level_first, td_bins.as<uint32_t>(),
+                                   chunks);
+                hipLaunchKernelGGL(k_td_split, dim3((level_n + MI_TD_SPLIT_BLOCK / 64 - 1) / (MI_TD_SPLIT_BLOCK / 64)), dim3(MI_TD_SPLIT_BLOCK), 0, st, td_nodes.as<TdNode>(), level_first, level_n, next_first, td_bins.as<uint32_t>(),
+                                   bx->as<BuildBox>(), c->nodes.as<float4>(), par_n.as<int>(), td_cnt.as<uint32_t>(), td_small.as<TdSmall>(), pad);
+                hipLaunchKernelGGL(k_td_flag, grid, block, 0, st, n, bx->as<BuildBox>(), nx->as<uint32_t>(), td_nodes.as<TdNode>(), flags.as<uint32_t>());
+                HIPCHK(hipcub::DeviceScan::ExclusiveSum(cub_tmp.p, scan_bytes, flags.as<uint32_t>(), vals_a.as<uint32_t>(), (int)n, st));
+                hipLaunchKernelGGL(k_td_scatter, grid, block, 0, st, n, bx->as<BuildBox>(), ix->as<uint32_t>(), nx->as<uint32_t>(), td_nodes.as<TdNode>(),
+                                   flags.as<uint32_t>(), vals_a.as<uint32_t>(), bx2->as<BuildBox>(), ix2->as<uint32_t>(), nx2->as<uint32_t>());
+                HIPCHK(hipGetLastError());
+                std::swap(bx, bx2); std::swap(ix, ix2); std::swap(nx, nx2);
+                HIPCHK(hipMemcpyAsync(cnt_h, td_cnt.p, 16, hipMemcpyDeviceToHost, st));
+                HIPCHK(hipStreamSynchronize(st));
+                if ((size_t)next_first + cnt_h[1] > cap_top || cnt_h[2] > cap_small) return fail(MI_ERR_HIP, "top-down build: node lists overflow");
+                level_first = next_first;
+                level_n = cnt_h[1];
+            }
+            // every remaining node: one wave each; the primitives of a job end in depth-first order
+            HIPCHK(hipMemcpyAsync(vals_b.p, ix->p, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
+            if (cnt_h[2])
+                hipLaunchKernelGGL(k_td_small, dim3((cnt_h[2] + 3) / 4), block, 0, st, cnt_h[2], td_small.as<TdSmall>(), bx->as<BuildBox>(), ix->as<uint32_t>(),
+                                   c->nodes.as<float4>(), par_n.as<int>(), td_cnt.as<uint32_t>(), vals_b.as<uint32_t>(), pad);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(cnt_h, td_cnt.p, 16, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            if (cnt_h[3] >= n - 1) return fail(MI_ERR_HIP, "top-down build: root %u of %u nodes", cnt_h[3], n - 1);
+            mi_status ps = permute_prims();
+            if (ps != MI_OK) return ps;
+            hipLaunchKernelGGL(k_td_fix_refs, ngrid, block, 0, st, n - 1, c->nodes.as<float4>(), vals_b.as<uint32_t>());
+            hipLaunchKernelGGL(k_nodes_area, ngrid, block, 0, st, n - 1, c->nodes.as<float4>(), area.as<double>());
+            root2 = (int32_t)cnt_h[3];
+        } else if (use_ploc) {
             // PLOC rounds: nearest neighbour in the window, merge mutual pairs, compact
             HIPCHK(ref_a.ensure((size_t)n * 4));
             HIPCHK(ref_t.ensure((size_t)n * 4));
@@ -1032,7 +1114,7 @@ MI_API mi_status mi_scene_upload_build(mi_ctx *c, const mi_scene_soa *s, const f
         built_depth = h_root;
         if (stats) {
             double a = 2.0 * (dx * dy + dy * dz + dz * dx);
-            if (use_ploc) { const double px = dx + 2.0 * pad, py = dy + 2.0 * pad, pz = dz + 2.0 * pad; a = 2.0 * (px * py + py * pz + pz * px); } // its boxes are summed padded
+            if (use_ploc || use_sah) { const double px = dx + 2.0 * pad, py = dy + 2.0 * pad, pz = dz + 2.0 * pad; a = 2.0 * (px * py + py * pz + pz * px); } // its boxes are summed padded
             stats->ms_build = ms;
             stats->sah_cost = a > 0 ? 1.0 + area_sum / a : 0.0;
             stats->depth = h_root;

@@ -37,7 +37,7 @@ int main(int argc, char **argv) {
             default:
                 std::cerr << "usage: " << argv[0] << " [options] [input.ray output.png]\n"
                           << "  -r <#>  recursion level (default 0)\n  -w <#>  image width (default 512)\n"
-                          << "  -s <#>  samples per dimension (default 2)\n  -G <#>  HIP device\n  -N <#>  number of GPUs (starting at -G), one process, tiles gathered over RCCL\n  -S <#>  RNG seed\n  -B      build the BVH on the GPU (PLOC; the default from 100000 primitives on)\n  -H      build the BVH on the host (binned SAH)\n";
+                          << "  -s <#>  samples per dimension (default 2)\n  -G <#>  HIP device\n  -N <#>  number of GPUs (starting at -G), one process, tiles gathered over RCCL\n  -S <#>  RNG seed\n  -B      build the BVH on the GPU (binned SAH; the default)\n  -H      build the BVH on the host (the same tree, seconds for a million primitives)\n";
                 return 1;
         }
     }

@@ -174,9 +174,8 @@ bool HipTracer::cubemapLoaded() {
 }
 
 bool HipTracer::wantsHostTree(size_t n_prims) {
-    size_t min_prims = TraceOptions::kDeviceBvhMinPrims;
-    if (const char *e = getenv("PT_DEVICE_BVH_MIN_PRIMS")) min_prims = (size_t)strtoull(e, nullptr, 10); // tuning / tests
-    device_tree_ = opts_.device_bvh > 0 || (opts_.device_bvh < 0 && n_prims >= min_prims);
+    (void)n_prims;
+    device_tree_ = opts_.device_bvh != 0;
     return !device_tree_;
 }
 

@@ -25,11 +25,10 @@ struct TraceOptions {
     int n_devices = 0;      // > 0: devices device .. device + n_devices - 1 as one mi_group (frame sharded by tile, RGBA8
                             // tiles gathered over RCCL); 0: one context on `device`
     unsigned long long seed = 0;
-    // Where the BVH is built: 1 on the GPU (mi_scene_upload_build: PLOC, milliseconds), 0 on the host (binned SAH: its
-    // trees render 1-4 % faster and cost ~2.4 us per primitive: 0.2 s for 82 k, 3.1 s for 1.3 M), -1 (default) on the GPU
-    // from kDeviceBvhMinPrims primitives on, where the host build would cost more than a frame's render many times over.
-    int device_bvh = -1;
-    static constexpr size_t kDeviceBvhMinPrims = 100000;
+    // Where the BVH is built: 1 (default) on the GPU (mi_scene_upload_build: top-down binned SAH, 2 ms for 82 k
+    // primitives, 9 ms for 1.3 M), 0 on the host (Scene::finalize: the same algorithm and — node for node — the same
+    // tree, at ~2.4 us per primitive: 0.2 s and 3.1 s).
+    int device_bvh = 1;
 };
 
 class Tracer {

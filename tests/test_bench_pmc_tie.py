@@ -25,13 +25,16 @@ def make_tree(tmp_path):
     return str(tmp_path)
 
 
-def test_matching_pass_is_used(tmp_path):
+def test_matching_pass_is_used(tmp_path, monkeypatch):
     root = make_tree(tmp_path)
     rec, stale = bench.pmc_record(WL, 1, "host", 1000, root)
     assert rec is not None and stale is None and rec["k_extend"]["lane_ops_sum"] == 1.0
     assert bench.pmc_record(WL, 2, "host", None, root)[0] is not None          # a shard: no frame ray count to compare
     assert bench.pmc_record("C2-cornell-512-64spp", 1, "host", 5, root) == (None, None)   # never profiled: absent, not stale
-    assert bench.pmc_record(WL, 1, "device", 1000, root) == (None, None)
+    assert bench.pmc_record(WL, 1, "device", 1000, root)[0] is not None         # the device's SAH build is the host's tree
+    monkeypatch.setenv("MI_TRACER_BUILDER", "ploc")
+    assert bench.pmc_record(WL, 1, "device", 1000, root) == (None, None)       # another tree: no pass on file
+    monkeypatch.delenv("MI_TRACER_BUILDER")
 
 
 def test_kernel_edit_without_a_new_pass_is_stale(tmp_path):

@@ -1,7 +1,7 @@
-"""Device-side BVH construction (mi_scene_upload_build): the LBVH is a valid
-tree over the caller's primitives, and — because the closest hit does not depend on the
-tree — renders and probes with it are bit-identical to the oracle, which walks the
-host-built SAH tree or tests every primitive."""
+"""Device-side BVH construction (mi_scene_upload_build): every builder (top-down binned SAH — the
+default —, PLOC, LBVH) gives a valid tree over the caller's primitives, the default one the very tree the host builder
+makes, and — because the closest hit does not depend on the tree — renders and probes with any of them are
+bit-identical to the oracle, which walks the host-built SAH tree or tests every primitive."""
 import ctypes as C
 
 import numpy as np
@@ -147,20 +147,72 @@ def test_device_build_rejects_bad_input(ctx, scenes_small):
 
 def test_device_build_quality_and_time_on_the_bench_scene(ctx, monkeypatch):
     sc = scenes.blob_scene(6)
-    st = ctx.upload_build(sc)                       # default builder: PLOC
+    st_s = ctx.upload_build(sc)                     # default builder: top-down binned SAH
+    dsah = ctx.scene_quality()
+    monkeypatch.setenv("MI_TRACER_BUILDER", "ploc")
+    st = ctx.upload_build(sc)
     ploc = ctx.scene_quality()
     monkeypatch.setenv("MI_TRACER_BUILDER", "lbvh")
     st_l = ctx.upload_build(sc)
     lbvh = ctx.scene_quality()
+    monkeypatch.setenv("MI_TRACER_BUILDER", "nonsense")
+    with pytest.raises(RuntimeError, match="MI_TRACER_BUILDER"):
+        ctx.upload_build(sc)
     monkeypatch.delenv("MI_TRACER_BUILDER")
     ctx.upload(sc)
     sah = ctx.scene_quality()
-    print(f"\nblob82k: PLOC {st.ms_build:.2f} ms depth {st.depth} SAH cost {ploc:.1f} | LBVH {st_l.ms_build:.2f} ms depth {st_l.depth} "
-          f"SAH cost {lbvh:.1f} | host binned SAH {sah:.1f}")
+    print(f"\nblob82k: device SAH {st_s.ms_build:.2f} ms depth {st_s.depth} SAH cost {dsah:.2f} | PLOC {st.ms_build:.2f} ms depth {st.depth} SAH cost "
+          f"{ploc:.2f} | LBVH {st_l.ms_build:.2f} ms depth {st_l.depth} SAH cost {lbvh:.2f} | host binned SAH {sah:.2f} depth {sc.bvh_depth}")
     assert st.depth <= 64 and st_l.depth <= 64 and 0.8 * sah <= ploc <= lbvh < 3.0 * sah
+    assert abs(dsah - sah) < 1e-5 * sah and st_s.depth == sc.bvh_depth and st_s.ms_build < 20.0
 
 
-@pytest.mark.parametrize("builder", ["lbvh", "ploc"])
+def same_tree(nodes_a, root_a, ids_a, nodes_b, root_b, ids_b):
+    """Two binary trees node for node: child boxes bit for bit, the same primitive in every leaf."""
+    refs_a, refs_b = nodes_a[:, 12:14].view(np.int32), nodes_b[:, 12:14].view(np.int32)
+    boxes_a, boxes_b = nodes_a[:, :12].view(np.uint32), nodes_b[:, :12].view(np.uint32)
+    stack, seen = [(root_a, root_b)], 0
+    while stack:
+        a, b = stack.pop()
+        seen += 1
+        if not np.array_equal(boxes_a[a], boxes_b[b]) and np.any(nodes_a[a, :12] != nodes_b[b, :12]):  # (-0.0 == +0.0)
+            return False
+        for c in range(2):
+            x, y = int(refs_a[a, c]), int(refs_b[b, c])
+            if (x < 0) != (y < 0) or (x < 0 and ids_a[~x] != ids_b[~y]):
+                return False
+            if x >= 0:
+                stack.append((x, y))
+    return seen == len(nodes_a) == len(nodes_b)
+
+
+def random_spheres(n, seed):
+    r = np.random.default_rng(seed)
+    body = ""
+    for _ in range(n):
+        x, y, z = r.uniform(-3, 3, 3)
+        body += f"translate({x:.5f},{y:.5f},{z:.5f}, scale({r.uniform(0.05, 0.4):.5f}, sphere {{ material = {{ diffuse = (1,1,1); }} }}))\n"
+    return P.Scene.from_text(H + CAM + body)
+
+
+def test_the_device_sah_builder_makes_the_host_builders_tree(ctx, scenes_small):
+    """The default device builder carries out host/scene.cpp's algorithm with its arithmetic: same splits, same child
+    order, same boxes, the same primitive in every leaf — around the 64-primitive hand-over from the level-by-level
+    phase to the one-wave phase, with triangles and spheres mixed, and on meshes."""
+    cases = [(f"spheres{n}", random_spheres(n, n)) for n in (2, 3, 5, 63, 64, 65, 66, 129, 200, 1000, 5000)]
+    cases += [(k, scenes_small[k]) for k in ("simple", "cornell", "glass", "blob3")] + [("blob5", scenes.blob_scene(5))]
+    for name, sc in cases:
+        ctx.upload(sc)
+        nodes_h, root_h = ctx.download_nodes()
+        ids_h = sc.array("prim_id", (sc.n_prims,), np.int32).copy()
+        st = ctx.upload_build(sc)
+        nodes_d, root_d = ctx.download_nodes()
+        ids_d = ctx.download_prim_ids()
+        assert st.depth == sc.bvh_depth, name
+        assert same_tree(nodes_h, root_h, ids_h, nodes_d, root_d, ids_d), name
+
+
+@pytest.mark.parametrize("builder", ["lbvh", "ploc", "sah"])
 def test_both_device_builders_give_valid_trees(ctx, scenes_small, monkeypatch, builder):
     monkeypatch.setenv("MI_TRACER_BUILDER", builder)
     for name in ("glass", "blob3"):

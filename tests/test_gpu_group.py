@@ -70,9 +70,9 @@ def test_tracer_and_cli_through_a_group(tmp_path, scenes_small):
     assert img is not None and np.array_equal(img, orgb)
 
 
-def test_cli_builds_large_scenes_on_the_gpu_by_default(tmp_path, scenes_small):
-    # pt::HipTracer builds the BVH on the GPU from 100000 primitives on (TraceOptions::device_bvh = -1); the threshold is
-    # lowered here so that a small scene takes that path: same image as with -H (host tree) and as the oracle's
+def test_cli_builds_the_tree_on_the_gpu_by_default(tmp_path, scenes_small):
+    # pt::HipTracer builds the BVH on the GPU (TraceOptions::device_bvh = 1; -H: on the host; MI_TRACER_BUILDER picks the
+    # device builder): same image every way, the oracle's
     import os
     text = scenes.blob_ray(3)
     sc = scenes_small["blob3"]
@@ -81,7 +81,7 @@ def test_cli_builds_large_scenes_on_the_gpu_by_default(tmp_path, scenes_small):
     ray = os.path.join(os.path.dirname(P.__file__), "bin", "ray")
     src = tmp_path / "b.ray"
     src.write_text(text)
-    for flags, env in (([], {"PT_DEVICE_BVH_MIN_PRIMS": "100"}), (["-H"], {"PT_DEVICE_BVH_MIN_PRIMS": "100"}), (["-B"], {}), ([], {})):
+    for flags, env in (([], {}), (["-H"], {}), (["-B"], {}), ([], {"MI_TRACER_BUILDER": "ploc"})):
         out = tmp_path / "o.bmp"
         r = subprocess.run([ray, "-r", "3", "-w", "120", "-s", "2", "-S", "7", *flags, str(src), str(out)], capture_output=True, text=True, timeout=120,
                            env={**os.environ, **env})
