@@ -976,7 +976,10 @@ MI_API mi_status mi_scene_upload_build(mi_ctx *c, const mi_scene_soa *s, const f
         if (use_sah) {
             // top-down binned SAH (mi_bvh_build.h): one tree level per round while nodes hold more than MI_TD_SMALL
             // primitives, then one wave per remaining node
-            const size_t cap_top = (size_t)n / 32 + 64, cap_small = (size_t)n / 2 + 1, cap_level = (size_t)n / 64 + 2;
+            // Bounds that hold for every input: a level's nodes own disjoint ranges of more than 64 positions, small jobs
+            // disjoint ranges of at least two; all top-phase nodes together are fewer than n (a chain that peels one
+            // primitive per level is possible: 36 levels of SAH splits, then halving).
+            const size_t cap_top = (size_t)n, cap_small = (size_t)n / 2 + 1, cap_level = (size_t)n / 64 + 2;
             HIPCHK(td_box_a.ensure((size_t)n * sizeof(BuildBox)));
             HIPCHK(td_box_b.ensure((size_t)n * sizeof(BuildBox)));
             HIPCHK(td_idx_a.ensure((size_t)n * 4));

@@ -212,6 +212,20 @@ def test_the_device_sah_builder_makes_the_host_builders_tree(ctx, scenes_small):
         assert same_tree(nodes_h, root_h, ids_h, nodes_d, root_d, ids_d), name
 
 
+def test_device_sah_builder_on_a_skewed_scene(ctx):
+    """Geometrically spaced spheres: every SAH split takes a few spheres off the far end — a deep, lopsided tree (the
+    top-phase node list is sized for that), valid, of bounded depth, with the same hits as a test of every primitive."""
+    body = "".join(f"translate({1.1 ** i:.4f},0,-3, scale({0.02 * 1.1 ** i:.5f}, sphere {{ material = {{ diffuse = (1,1,1); }} }}))\n" for i in range(260))
+    sc = P.Scene.from_text(H + CAM + body)
+    st = ctx.upload_build(sc)
+    nodes, root = ctx.download_nodes()
+    lo, hi, _ = device_bounds(ctx, sc)
+    assert 16 < check_tree(nodes, root, lo, hi) == st.depth <= 64
+    ids, t, _ = ctx.trace_primary(64, 64, 1)
+    oi, ot, _, _ = O.trace_primary(sc, 64, 64, 1, O.BRUTE)
+    assert np.array_equal(ids, oi) and same(t, ot)
+
+
 @pytest.mark.parametrize("builder", ["lbvh", "ploc", "sah"])
 def test_both_device_builders_give_valid_trees(ctx, scenes_small, monkeypatch, builder):
     monkeypatch.setenv("MI_TRACER_BUILDER", builder)
