@@ -212,6 +212,53 @@ def test_the_device_sah_builder_makes_the_host_builders_tree(ctx, scenes_small):
         assert same_tree(nodes_h, root_h, ids_h, nodes_d, root_d, ids_d), name
 
 
+def soup_scene(seed):
+    """Random scene for the builder: spheres, triangle soups, centroids on a lattice (many coincident), collinear flat
+    and zero-area triangles (scratch/sah_soak.py runs 1500 of these)."""
+    r = np.random.default_rng(seed)
+    n = int(r.choice([2, 3, 7, 40, 64, 65, 100, 300, 1000]))
+    kind = seed % 5
+    body, pts, faces = "", [], []
+    for i in range(n):
+        if kind == 0 or (kind == 4 and i % 2):
+            x, y, z = r.uniform(-3, 3, 3)
+            body += f"translate({x:.5f},{y:.5f},{z:.5f}, scale({r.uniform(0.01, 0.5):.5f}, sphere {{ material = {{ diffuse = (1,1,1); }} }}))\n"
+            continue
+        if kind == 2:
+            c = r.integers(-2, 3, 3).astype(float)
+        elif kind == 3:
+            c = np.array([r.uniform(-3, 3), 0.0, 0.0])
+        else:
+            c = r.uniform(-3, 3, 3)
+        e = 0.0 if (kind == 3 and i % 7 == 0) else r.uniform(0.01, 0.6)
+        a, b = r.normal(size=3) * e, r.normal(size=3) * e
+        if kind == 3:
+            a[1:] = 0.0
+            b[1:] = 0.0
+        k = len(pts)
+        pts += [c - (a + b) / 3, c + a - (a + b) / 3, c + b - (a + b) / 3]
+        faces.append((k, k + 1, k + 2))
+    if faces:
+        body += ("polymesh { points = (" + ",".join(f"({q[0]:.6f},{q[1]:.6f},{q[2]:.6f})" for q in pts) + "); faces = ("
+                 + ",".join(f"({a},{b},{c})" for a, b, c in faces) + "); material = { diffuse = (0.5,0.5,0.5); } }\n")
+    return P.Scene.from_text(H + CAM + body)
+
+
+def test_device_sah_builder_fuzz(ctx):
+    for seed in range(60):
+        sc = soup_scene(seed)
+        if sc.n_prims < 2:
+            continue
+        ctx.upload(sc)
+        nodes_h, root_h = ctx.download_nodes()
+        ids_h = sc.array("prim_id", (sc.n_prims,), np.int32).copy()
+        st = ctx.upload_build(sc)
+        nodes_d, root_d = ctx.download_nodes()
+        lo, hi, _ = device_bounds(ctx, sc)
+        assert check_tree(nodes_d, root_d, lo, hi) == st.depth == sc.bvh_depth, seed
+        assert same_tree(nodes_h, root_h, ids_h, nodes_d, root_d, ctx.download_prim_ids()), seed
+
+
 def test_device_sah_builder_on_a_skewed_scene(ctx):
     """Geometrically spaced spheres: every SAH split takes a few spheres off the far end — a deep, lopsided tree (the
     top-phase node list is sized for that), valid, of bounded depth, with the same hits as a test of every primitive."""
