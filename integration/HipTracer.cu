@@ -10,7 +10,7 @@
 #include "scene/cubeMap.h"
 #include "scene/material.h"
 
-HipTracer::HipTracer(TraceUI *ui) : Tracer(ui), seed(ui->m_seed) {
+HipTracer::HipTracer(TraceUI *ui) : Tracer(ui), seed(ui->m_seed), own_tree(ui->m_hipOwnTree) {
     status = mi_ctx_create(ui->m_hipDevice, &ctx);          // replaces GpuTracer's implicit device 0 (GpuTracer.cu:165-181)
     if (status != MI_OK) std::cerr << "HipTracer: " << mi_last_error() << std::endl;
 }
@@ -59,7 +59,7 @@ bool HipTracer::flatten() {
     uint32_t t = 0, s = 0;
     for (size_t i = 0; i < n; i++) slot_of[i] = actual[i].isSphere ? (int32_t)(n_tri + s++) : (int32_t)t++;
 
-    for (auto *v : {&nodes, &tri_v0, &tri_uinv, &tri_vinv, &tri_ninv, &tri_normal, &sph, &mats}) v->clear();
+    for (auto *v : {&nodes, &tri_v0, &tri_uinv, &tri_vinv, &tri_ninv, &tri_normal, &sph, &mats, &tri_verts}) v->clear();
     tri_mat.clear(); sph_mat.clear(); tri_has_vmat.clear();
     prim_id.assign(n, 0);
     MatTable table{{}, &mats};
@@ -74,6 +74,7 @@ bool HipTracer::flatten() {
             const TrimeshFace &f = g.obj.face;                                 // trimesh.h:17-23
             put4(tri_v0, f.vertices[0]);                                       // trimesh.cu:88 reads vertices[0]
             put4(tri_uinv, f.uInv); put4(tri_vinv, f.vInv); put4(tri_ninv, f.nInv); put4(tri_normal, f.normal);
+            for (int k = 0; k < 3; k++) for (int a = 0; a < 3; a++) tri_verts.push_back(f.vertices[k][a]);   // for -B: the boxes of geometry.h:13-29
             tri_has_vmat.push_back(f.hasMaterials ? 1 : 0);
             for (int k = 0; k < 3; k++) tri_mat.push_back(table.add(f.materials[f.hasMaterials ? k : 0]));   // trimesh.cu:40-45
         }
@@ -112,7 +113,11 @@ bool HipTracer::flatten() {
     soa.prim_id = prim_id.data();
     const Camera &cam = scene->getCamera();                                    // camera.h:33-36
     for (int k = 0; k < 4; k++) { soa.cam_eye[k] = cam.eye[k]; soa.cam_u[k] = cam.u[k]; soa.cam_v[k] = cam.v[k]; soa.cam_look[k] = cam.look[k]; }
-    status = mi_scene_upload(ctx, &soa);                                       // validates refs, coverage and depth on the host
+    // Either the reference's own hierarchy, validated on the host (refs, coverage, depth), or (-B) a tree the library
+    // builds on the GPU from the primitives alone — binned SAH, 2 ms for 82 k triangles — in which case `nodes` is
+    // ignored.  The image is the same either way (the closest hit does not depend on the tree: mi_scene_soa.prim_id);
+    // the frame rate is not: the kernels' rate on a mesh follows the tree's quality (report §5.2).
+    status = own_tree ? mi_scene_upload_build(ctx, &soa, tri_verts.data(), nullptr) : mi_scene_upload(ctx, &soa);
     if (status != MI_OK) std::cerr << "HipTracer: " << mi_last_error() << std::endl;
     return status == MI_OK;
 }

@@ -9,9 +9,10 @@
 // Edits to existing reference files (all one-liners):
 //   src/tracer.h          after the GpuTracer declaration:   #include "../integration/HipTracer.h"
 //   src/main.cu:10-11     ui->m_hip ? ui->setRayTracer(new HipTracer(ui)) : ui->m_gpu ? ... GpuTracer ... : ... CpuTracer ...
-//   src/ui/TraceUI.h:47   bool m_hip = false; int m_hipDevice = 0; unsigned long long m_seed = 0;
-//   src/ui/CommandLineUI.cu:27   getopt string "t:r:w:hj:c:s:gq:G:S:";  case 'G': m_hip = true; m_hipDevice = atoi(optarg); break;
+//   src/ui/TraceUI.h:47   bool m_hip = false, m_hipOwnTree = false; int m_hipDevice = 0; unsigned long long m_seed = 0;
+//   src/ui/CommandLineUI.cu:27   getopt string "t:r:w:hj:c:s:gq:G:S:B";  case 'G': m_hip = true; m_hipDevice = atoi(optarg); break;
 //                                case 'S': m_seed = strtoull(optarg, nullptr, 10); break;
+//                                case 'B': m_hipOwnTree = true; break;   // the library builds its own BVH on the GPU
 //   src/scene/bvh.h:44    class BoundedVolumeHierarchy { friend class HipTracer; ...   (root is private)
 //   src/scene/geometry.h:40   friend class HipTracer;                                   (the Sphere|TrimeshFace union is private)
 //   src/scene/trimesh.h:22, sphere.h:16, camera.h:28, material.h:121, cubeMap.h:11, material.h:52 (TextureMap)
@@ -50,7 +51,8 @@ private:
     bool cube_valid = false;
     std::thread worker;
     // storage behind the borrowed pointers of `soa`
-    std::vector<float> nodes, tri_v0, tri_uinv, tri_vinv, tri_ninv, tri_normal, sph, mats;
+    std::vector<float> nodes, tri_v0, tri_uinv, tri_vinv, tri_ninv, tri_normal, sph, mats, tri_verts;
+    bool own_tree = false;                    // -B: mi_scene_upload_build instead of the reference's Cluster tree
     std::vector<uint32_t> tri_mat, sph_mat;
     std::vector<uint8_t> tri_has_vmat;
     std::vector<int32_t> prim_id;
