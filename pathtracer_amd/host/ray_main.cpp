@@ -6,7 +6,7 @@
 // overrides are outside this backend's scope), -c <one of the six face files> loads the
 // cubemap background (CommandLineUI.cu:40-42,66-68).
 // Added: -G <device>, -N <GPUs> (devices -G .. -G + N - 1 render tile shards of the frame in one process, tiles gathered
-// over RCCL), -S <seed>, -B / -H (build the BVH on the GPU / on the host; default: GPU from 100000 primitives on).
+// over RCCL), -S <seed>, -B / -H (build the BVH on the GPU / on the host; default: on the GPU, the same tree).
 #include <unistd.h>
 
 #include <cmath>
