@@ -850,6 +850,7 @@ k_extend(DevScene sc, const uint32_t *count_ptr, uint32_t fixed_count, uint32_t 
             }
             more = rng_next < rng_end || chunk < n_chunks;
         }
+        if (!more) break; // nothing left to refill with: the drain loop below takes over
         if (COUNT) wave_iters++;
 #ifdef MI_WAVE_TIMES
         wt_iters++;
@@ -858,18 +859,11 @@ k_extend(DevScene sc, const uint32_t *count_ptr, uint32_t fixed_count, uint32_t 
         const bool want_node = active && lane_wants_node(L);
         const int nl = __popcll(__ballot(want_leaf)), nn = __popcll(__ballot(want_node));
         if (COUNT && lane == 0) { // lane slots of this iteration by state (instrumented variant only)
-            const bool leaf_it = !more ? false : (nl > 0 && (nl >= leaf_min || nn == 0));
-            if (!more) { dbg_cnt[3] += (uint32_t)(64 - nl - nn); dbg_cnt[4] += (uint32_t)(nl + nn); }   // draining: idle / working
-            else if (leaf_it) { dbg_cnt[0] += (uint32_t)(64 - nl - nn); dbg_cnt[1] += (uint32_t)nn; dbg_cnt[5] += (uint32_t)nl; }  // leaf phase: empty / waiting for node / working
+            const bool leaf_it = nl > 0 && (nl >= leaf_min || nn == 0);
+            if (leaf_it) { dbg_cnt[0] += (uint32_t)(64 - nl - nn); dbg_cnt[1] += (uint32_t)nn; dbg_cnt[5] += (uint32_t)nl; }  // leaf phase: empty / waiting for node / working
             else { dbg_cnt[0] += (uint32_t)(64 - nl - nn); dbg_cnt[2] += (uint32_t)nl; dbg_cnt[6] += (uint32_t)nn; }              // node phase: empty / waiting for leaf / working
         }
-        if (!more) {
-            // Draining (no rays left to refill with): the wave's remaining time is a latency
-            // chain, so every lane advances every iteration, leaves and nodes both.
-            if (COUNT && want_leaf) n_leaves++;
-            if (COUNT && want_node) { n_nodes++; ray_steps++; }
-            merged_step<ANY>(sc, L, stack, my_ovf, ovf_stride, nbase, want_leaf, want_node);
-        } else if (nl > 0 && (nl >= leaf_min || nn == 0)) {
+        if (nl > 0 && (nl >= leaf_min || nn == 0)) {
             if (want_leaf) {
                 if (COUNT) n_leaves++;
                 leaf_phase(sc, L, stack, my_ovf, ovf_stride);
@@ -888,7 +882,33 @@ k_extend(DevScene sc, const uint32_t *count_ptr, uint32_t fixed_count, uint32_t 
             if (COUNT) { max_ray_steps = max(max_ray_steps, ray_steps); ray_steps = 0; }
         }
         act = __ballot(active);
-    } while (more || act != 0ull);
+    } while (true);
+    // Draining (no rays left to refill with): the wave's remaining time is a latency chain, so every lane advances
+    // every iteration, leaves and nodes both (merged_step).  A loop of its own: with the drain as a third branch of
+    // the loop above, C3 ran 1.4 % and C5 1.7 % slower (the steady loop carries no test of `more`, the drain loop no
+    // refill; each has one back edge).
+    act = __ballot(active); // (`act` predates the last refill)
+    while (act != 0ull) {
+        const bool want_leaf = active && lane_wants_leaf(L);
+        const bool want_node = active && lane_wants_node(L);
+#ifdef MI_WAVE_TIMES
+        wt_iters++;
+#endif
+        if (COUNT) {
+            wave_iters++;
+            const int nl = __popcll(__ballot(want_leaf)), nn = __popcll(__ballot(want_node));
+            if (lane == 0) { dbg_cnt[3] += (uint32_t)(64 - nl - nn); dbg_cnt[4] += (uint32_t)(nl + nn); }
+            if (want_leaf) n_leaves++;
+            if (want_node) { n_nodes++; ray_steps++; }
+        }
+        merged_step<ANY>(sc, L, stack, my_ovf, ovf_stride, nbase, want_leaf, want_node);
+        if (active && lane_done(L)) {
+            hits[slot] = make_float2(L.h.t, __int_as_float(L.h.slot));
+            active = false;
+            if (COUNT) { max_ray_steps = max(max_ray_steps, ray_steps); ray_steps = 0; }
+        }
+        act = __ballot(active);
+    }
     if (PRIMARY && lane == 0 && n_primary) atomicAdd(primary_count, n_primary);
 #ifdef MI_WAVE_TIMES
     // Diagnostic build (-DMI_WAVE_TIMES, MI_TRACER_WAVE_TIMES=<file>; scratch/wt.sh, scratch/wt.py): when each wave
