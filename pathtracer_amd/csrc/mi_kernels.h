@@ -796,7 +796,7 @@ k_extend(DevScene sc, const uint32_t *count_ptr, uint32_t fixed_count, uint32_t 
         // this wave's current chunk range, so rays of different traversal length do not
         // leave lanes idle for the rest of a 64-ray packet.
         const int n_idle = 64 - __popcll(act);
-        if (more && (n_idle >= refill_min || act == 0ull)) {
+        if (more) { // (the loop around the phases below ends when a refill is due)
             if (rng_next >= rng_end && chunk < n_chunks) {
                 stream_chunk(count_ptr, fixed_count, segcap, chunk, rng_next, rng_end);
                 rng_next = __builtin_amdgcn_readfirstlane(rng_next);
@@ -851,6 +851,7 @@ k_extend(DevScene sc, const uint32_t *count_ptr, uint32_t fixed_count, uint32_t 
             more = rng_next < rng_end || chunk < n_chunks;
         }
         if (!more) break; // nothing left to refill with: the drain loop below takes over
+        do { // phases until at least refill_min lanes are idle: the refill code stays out of the hot loop (C5 -1.2 %, C3 -0.4 %)
         if (COUNT) wave_iters++;
 #ifdef MI_WAVE_TIMES
         wt_iters++;
@@ -882,6 +883,7 @@ k_extend(DevScene sc, const uint32_t *count_ptr, uint32_t fixed_count, uint32_t 
             if (COUNT) { max_ray_steps = max(max_ray_steps, ray_steps); ray_steps = 0; }
         }
         act = __ballot(active);
+        } while (act != 0ull && 64 - __popcll(act) < refill_min);
     } while (true);
     // Draining (no rays left to refill with): the wave's remaining time is a latency chain, so every lane advances
     // every iteration, leaves and nodes both (merged_step).  A loop of its own: with the drain as a third branch of
