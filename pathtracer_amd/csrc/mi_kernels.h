@@ -760,9 +760,11 @@ k_extend(DevScene sc, const uint32_t *count_ptr, uint32_t fixed_count, uint32_t 
     // Work distribution in 64-ray chunks, dealt statically and interleaved over the waves
     // (wave w takes virtual chunks w, w+W, w+2W, ...): no atomics (a work cursor on one
     // word cost 6 of 7 ms at level 0), and every wave sees the same mix of image regions.
-    // Wave-uniform bookkeeping is kept in SGPRs (readfirstlane) and the loop has a single
-    // back edge and no `continue`: with a more tangled control flow the compiler copies
-    // the whole per-lane state (≈45 v_mov) on every iteration.
+    // Wave-uniform bookkeeping is kept in SGPRs (readfirstlane).  The shape of the loops matters as much as what is
+    // in them: three plain loops, each with one back edge and no `continue` — the steady loop (refill, then an inner
+    // loop of phases that ends when the next refill is due) and the drain loop behind it.  As ONE loop with the drain
+    // as a third branch and the refill test inside, the frame was 2 % slower; with a more tangled control flow the
+    // compiler copies the whole per-lane state (≈45 v_mov) on every iteration.
     const uint32_t n_waves = gridDim.x * (MI_BLOCK / 64);
     const uint32_t wave_id = __builtin_amdgcn_readfirstlane(blockIdx.x * (MI_BLOCK / 64) + (threadIdx.x >> 6));
     const uint32_t n_chunks = stream_chunks(count_ptr, fixed_count);
