@@ -8,7 +8,9 @@ CXX ?= g++
 ARCH ?= gfx950
 # -ffp-contract=off: the numerics contract — no FMA contraction, so
 # device results match the oracle bit for bit.
-HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function $(EXTRA_HIPFLAGS)
+# -fno-slp-vectorize: left to itself the SLP vectorizer pairs scalar fp32 operations of the traversal and shading code into
+# v_pk_mul_f32 / v_pk_add_f32 (same results; IEEE either way), which costs every workload 2-3 % (C3 5.95 -> 5.81 ms, C2 -3.3 %).
+HIPFLAGS = --offload-arch=$(ARCH) -O3 -fno-slp-vectorize -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function $(EXTRA_HIPFLAGS)
 # make WIDE8=1: the 8-wide node format (mi_trav8.h, mi_wide8.h) instead of the quantised 4-wide one
 ifeq ($(WIDE8),1)
 HIPFLAGS += -DMI_WIDE8

@@ -438,7 +438,7 @@ def main():
         dist.destroy_process_group()
 
 
-KERNEL_SOURCES = ("pathtracer_amd/csrc/mi_kernels.h", "pathtracer_amd/csrc/mi_tracer.hip", "pathtracer_amd/csrc/mi_bvh_build.h")
+KERNEL_SOURCES = ("pathtracer_amd/csrc/mi_kernels.h", "pathtracer_amd/csrc/mi_tracer.hip", "pathtracer_amd/csrc/mi_bvh_build.h", "Makefile")  # the Makefile for its compiler flags
 
 
 def device_builder():
